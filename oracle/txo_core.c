@@ -1,0 +1,650 @@
+/*
+ * txo_core.c -- ORACLE (test infrastructure only; see txoracle.h): key generation, encryption,
+ * and the circuit-bootstrapping primitives a4..a10 of SURVEY.md section 8, restated from the
+ * reference files cited at each function.
+ */
+#include "txoracle.h"
+#include "txo_internal.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+#include <malloc.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+void txo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int txo_get_threads(void) { return g_threads; }
+
+void txo_params_aes_tight(txo_params *p)
+{   /* cbs_lib/src/aes_instances.rs:76-97 */
+    p->n = 768; p->N = 1024; p->k = 2;
+    p->pbs_base_log = 23; p->pbs_level = 1;
+    p->ks_base_log = 4; p->ks_level = 3; p->ks_N = 256;
+    p->auto_base_log = 13; p->auto_level = 3; p->auto_split = 41;
+    p->ss_base_log = 17; p->ss_level = 2;
+    p->cbs_base_log = 2; p->cbs_level = 7;
+    p->log_lut_count = 3;
+    p->lwe_std = 0.00000702047462940120;
+    p->glwe_std = 0.00000000000000029403601535432533;
+}
+
+static uint32_t ilog2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) l++; return l; }
+
+size_t txo_bsk_words(const txo_params *p)  { size_t K = p->k + 1; return (size_t)p->n * p->pbs_level * K * K * p->N; }
+size_t txo_ksk_words(const txo_params *p)  { return (size_t)(p->k * p->N / p->ks_N) * p->ks_level * (p->n / p->ks_N + 1) * p->ks_N; }
+size_t txo_auto_words(const txo_params *p) { size_t K = p->k + 1; return (size_t)ilog2(p->N) * p->k * p->auto_level * K * p->N; }
+size_t txo_ss_words(const txo_params *p)   { size_t K = p->k + 1; return (size_t)p->k * p->ss_level * K * K * p->N; }
+size_t txo_lut_words(const txo_params *p)  { size_t K = p->k + 1; return (size_t)(9 * 4 + 1) * 16 * 2 * K * p->N; }
+size_t txo_ctr_lut_words(const txo_params *p) { size_t K = p->k + 1; return (size_t)10 * 3 * 16 * 2 * K * p->N; }
+
+/* ---------------- random numbers (deterministic test generator, not a CSPRNG) ---------------- */
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+void txo_rng_seed(txo_rng *r, uint64_t seed)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 4; i++) {
+        z += 0x9E3779B97F4A7C15ull;
+        uint64_t t = z;
+        t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ull;
+        t = (t ^ (t >> 27)) * 0x94D049BB133111EBull;
+        r->s[i] = t ^ (t >> 31);
+    }
+    r->have_spare = 0;
+}
+uint64_t txo_rng_u64(txo_rng *r)
+{
+    uint64_t *s = r->s;
+    uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return result;
+}
+static double rng_unit(txo_rng *r) { return ((double)(txo_rng_u64(r) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+double txo_rng_gauss(txo_rng *r)
+{
+    if (r->have_spare) { r->have_spare = 0; return r->spare; }
+    double u = rng_unit(r), v = rng_unit(r);
+    double m = sqrt(-2.0 * log(u));
+    r->spare = m * sin(6.283185307179586476925 * v); r->have_spare = 1;
+    return m * cos(6.283185307179586476925 * v);
+}
+/* torus noise: round(gauss * std * 2^64) (tfhe: Gaussian sampled on the real torus, scaled) */
+uint64_t txo_rng_noise(txo_rng *r, double std)
+{
+    double e = txo_rng_gauss(r) * std * 18446744073709551616.0;
+    return (uint64_t)(int64_t)llrint(e);
+}
+
+/* ---------------- polynomial helpers ---------------- */
+/* out = in * X^s  (mod X^N + 1), s taken mod 2N */
+void txo_poly_rotate(uint32_t N, const uint64_t *in, int64_t s, uint64_t *out)
+{
+    uint32_t twoN = 2 * N;
+    uint32_t sh = (uint32_t)(((s % (int64_t)twoN) + twoN) % twoN);
+    for (uint32_t i = 0; i < N; i++) {
+        uint32_t d = i + sh;
+        d %= twoN;
+        if (d < N) out[d] = in[i]; else out[d - N] = (uint64_t)0 - in[i];
+    }
+}
+/* automorphism X -> X^t, t odd  (cbs_lib/src/utils.rs:475-490) */
+void txo_poly_auto(uint32_t N, const uint64_t *in, uint32_t t, uint64_t *out)
+{
+    out[0] = in[0];
+    for (uint32_t i = 1; i < N; i++) {
+        uint64_t it = (uint64_t)i * t;
+        uint32_t j = (uint32_t)(it % N);
+        out[j] = ((it / N) & 1) ? (uint64_t)0 - in[i] : in[i];
+    }
+}
+/* exact binary-secret product: out += sign * a * s  (s has 0/1 coefficients) */
+static void poly_mul_binary_acc(uint32_t N, const uint64_t *a, const uint64_t *s, uint64_t *out, int sub)
+{
+    for (uint32_t i = 0; i < N; i++) {
+        if (!s[i]) continue;
+        for (uint32_t j = 0; j < N; j++) {
+            uint32_t d = i + j;
+            uint64_t v = a[j];
+            if (d >= N) { d -= N; v = (uint64_t)0 - v; }
+            if (sub) out[d] -= v; else out[d] += v;
+        }
+    }
+}
+/* same with a general small signed multiplier polynomial (used by key generation) */
+static void poly_mul_small_acc(uint32_t N, const uint64_t *a, const int64_t *s, uint64_t *out)
+{
+    for (uint32_t i = 0; i < N; i++) {
+        if (!s[i]) continue;
+        uint64_t m = (uint64_t)s[i];
+        for (uint32_t j = 0; j < N; j++) {
+            uint32_t d = i + j;
+            uint64_t v = a[j] * m;
+            if (d >= N) { d -= N; v = (uint64_t)0 - v; }
+            out[d] += v;
+        }
+    }
+}
+
+/* ---------------- tfhe-rs primitives restated ---------------- */
+/* SignedDecomposer::{closest_representable, decompose}; digits[0] = level `level` (finest) */
+void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digits)
+{
+    uint32_t nonrep = 64 - base_log * level;
+    uint64_t r = x;
+    if (nonrep > 0) {
+        r = x >> (nonrep - 1);
+        r += 1;
+        r &= ~(uint64_t)1;
+        r <<= (nonrep - 1);
+    }
+    uint64_t state = nonrep ? (r >> nonrep) : r;
+    uint64_t mask = ((uint64_t)1 << base_log) - 1;
+    for (uint32_t i = 0; i < level; i++) {
+        uint64_t res = state & mask;
+        state >>= base_log;
+        uint64_t carry = ((res - 1) | state) & res;
+        carry >>= (base_log - 1);
+        state += carry;
+        digits[i] = (int64_t)(res - (carry << base_log));
+    }
+}
+/* fast_pbs_modulus_switch(x, N, offset 0, lut_count_log) */
+uint32_t txo_modswitch(uint64_t x, uint32_t log2N, uint32_t log_lut_count)
+{
+    uint64_t o = x >> (64 - log2N - 2 + log_lut_count);
+    o += (o & 1);
+    o >>= 1;
+    o <<= log_lut_count;
+    return (uint32_t)o;
+}
+/* extract_lwe_sample_from_glwe_ciphertext at coefficient nth */
+void txo_sample_extract(const txo_params *p, const uint64_t *glwe, uint32_t nth, uint64_t *lwe)
+{
+    uint32_t N = p->N, k = p->k;
+    for (uint32_t q = 0; q < k; q++) {
+        const uint64_t *a = glwe + (size_t)q * N;
+        uint64_t *m = lwe + (size_t)q * N;
+        for (uint32_t j = 0; j <= nth; j++) m[j] = a[nth - j];
+        for (uint32_t j = nth + 1; j < N; j++) m[j] = (uint64_t)0 - a[N + nth - j];
+    }
+    lwe[(size_t)k * N] = glwe[(size_t)k * N + nth];
+}
+
+/* ---------------- encryption ---------------- */
+/* GLWE encryption of the plaintext polynomial pt (already scaled), fresh uniform mask */
+void txo_glwe_encrypt(const txo_params *p, txo_rng *rng, const uint64_t *sk, const uint64_t *pt,
+                      double std, uint64_t *out)
+{
+    uint32_t N = p->N, k = p->k;
+    uint64_t *b = out + (size_t)k * N;
+    for (uint32_t j = 0; j < N; j++) b[j] = (pt ? pt[j] : 0) + txo_rng_noise(rng, std);
+    for (uint32_t q = 0; q < k; q++) {
+        uint64_t *a = out + (size_t)q * N;
+        for (uint32_t j = 0; j < N; j++) a[j] = txo_rng_u64(rng);
+        poly_mul_binary_acc(N, a, sk + (size_t)q * N, b, 0);
+    }
+}
+static void glwe_encrypt_dims(uint32_t N, uint32_t k, txo_rng *rng, const uint64_t *sk, const uint64_t *pt,
+                              double std, uint64_t *out)
+{
+    txo_params q; memset(&q, 0, sizeof q); q.N = N; q.k = k;
+    txo_glwe_encrypt(&q, rng, sk, pt, std, out);
+}
+
+void txo_lwe_encrypt_bits(const txo_params *p, uint64_t seed, const uint64_t *sk, uint32_t dim,
+                          double std, const uint8_t *bits, size_t count, uint64_t *out)
+{
+    (void)p;
+    txo_rng rng; txo_rng_seed(&rng, seed);
+    for (size_t c = 0; c < count; c++) {
+        uint64_t *ct = out + c * (dim + 1);
+        uint64_t b = ((uint64_t)(bits[c] & 1) << 63) + txo_rng_noise(&rng, std);
+        for (uint32_t j = 0; j < dim; j++) { ct[j] = txo_rng_u64(&rng); if (sk[j]) b += ct[j]; }
+        ct[dim] = b;
+    }
+}
+void txo_lwe_phase(const uint64_t *sk, uint32_t dim, const uint64_t *ct, size_t count, uint64_t *phase)
+{
+    for (size_t c = 0; c < count; c++) {
+        const uint64_t *x = ct + c * (dim + 1);
+        uint64_t b = x[dim];
+        for (uint32_t j = 0; j < dim; j++) if (sk[j]) b -= x[j];
+        phase[c] = b;
+    }
+}
+void txo_lwe_decrypt_bits(const uint64_t *sk, uint32_t dim, const uint64_t *ct, size_t count, uint8_t *bits)
+{   /* submission/src/help_fun.rs:24-43 */
+    for (size_t c = 0; c < count; c++) {
+        uint64_t ph; txo_lwe_phase(sk, dim, ct + c * (dim + 1), 1, &ph);
+        uint64_t rounding = (ph & ((uint64_t)1 << 62)) << 1;
+        bits[c] = (uint8_t)(((ph + rounding) >> 63) & 1);
+    }
+}
+void txo_glwe_phase(const txo_params *p, const uint64_t *sk, const uint64_t *glwe, uint64_t *phase)
+{
+    uint32_t N = p->N, k = p->k;
+    memcpy(phase, glwe + (size_t)k * N, sizeof(uint64_t) * N);
+    for (uint32_t q = 0; q < k; q++) poly_mul_binary_acc(N, glwe + (size_t)q * N, sk + (size_t)q * N, phase, 1);
+}
+
+/* ---------------- key generation ---------------- */
+/* GGSW of a small signed polynomial message m(X) (tfhe encrypt_constant_ggsw_ciphertext
+ * generalised to a polynomial): row (lev, r<k) encrypts -m*s_r*2^(64-B lev); row (lev,k)
+ * encrypts m*2^(64-B lev).  Layout [lev][row][poly][N], level 1 first. */
+static void ggsw_encrypt_poly(const txo_params *p, txo_rng *rng, const uint64_t *sk, const int64_t *m,
+                              uint32_t B, uint32_t l, double std, uint64_t *out)
+{
+    uint32_t N = p->N, k = p->k, K = k + 1;
+    uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    for (uint32_t lev = 0; lev < l; lev++) {
+        uint32_t sh = 64 - B * (lev + 1);
+        for (uint32_t r = 0; r < K; r++) {
+            memset(pt, 0, sizeof(uint64_t) * N);
+            if (r < k) {
+                poly_mul_small_acc(N, sk + (size_t)r * N, m, pt);      /* m * s_r */
+                for (uint32_t j = 0; j < N; j++) pt[j] = ((uint64_t)0 - pt[j]) << sh;
+            } else {
+                for (uint32_t j = 0; j < N; j++) pt[j] = ((uint64_t)m[j]) << sh;
+            }
+            txo_glwe_encrypt(p, rng, sk, pt, std, out + ((size_t)lev * K + r) * K * N);
+        }
+    }
+    free(pt);
+}
+
+void txo_keygen(const txo_params *p, uint64_t seed, uint64_t *lwe_sk, uint64_t *glwe_sk,
+                uint64_t *bsk, uint64_t *ksk, uint64_t *auto_keys, uint64_t *ss_key)
+{
+    uint32_t N = p->N, k = p->k, K = k + 1, n = p->n;
+    txo_rng rng; txo_rng_seed(&rng, seed);
+    /* keygen.rs:208-217: binary secrets */
+    for (uint32_t i = 0; i < n; i++) lwe_sk[i] = txo_rng_u64(&rng) & 1;
+    for (uint32_t i = 0; i < k * N; i++) glwe_sk[i] = txo_rng_u64(&rng) & 1;
+
+    /* keygen.rs:219-227: bsk[i] = GGSW(s_lwe[i]) under the GLWE key, glwe noise */
+    int64_t *m = (int64_t *)calloc(N, sizeof(int64_t));
+    for (uint32_t i = 0; i < n; i++) {
+        m[0] = (int64_t)lwe_sk[i];
+        ggsw_encrypt_poly(p, &rng, glwe_sk, m, p->pbs_base_log, p->pbs_level, p->glwe_std,
+                          bsk + (size_t)i * p->pbs_level * K * K * N);
+    }
+    m[0] = 0;
+
+    /* keygen.rs:230-240 + glwe_keyswitch.rs:183-218 + glev_ciphertext.rs:134-173:
+     * GLWE-form key switch key at N_c = ks_N from the big key to the small key, lwe noise.
+     * ksk[p] = GLev (level 1 first) of -s_in_p under s_out */
+    {
+        uint32_t Nc = p->ks_N, kin = k * N / Nc, kout = n / Nc, Kout = kout + 1;
+        uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * Nc);
+        for (uint32_t q = 0; q < kin; q++)
+            for (uint32_t lev = 0; lev < p->ks_level; lev++) {
+                uint32_t sh = 64 - p->ks_base_log * (lev + 1);
+                for (uint32_t j = 0; j < Nc; j++) pt[j] = ((uint64_t)0 - glwe_sk[(size_t)q * Nc + j]) << sh;
+                glwe_encrypt_dims(Nc, kout, &rng, lwe_sk, pt, p->lwe_std,
+                                  ksk + ((size_t)q * p->ks_level + lev) * Kout * Nc);
+            }
+        free(pt);
+    }
+
+    /* automorphism.rs:62-120,152-178: for i = 1..log2 N, t = N/2^(i-1)+1: key switch key from
+     * S(X^t) to S(X): key[p] = GLev of -(s_p(X^t)), glwe noise */
+    {
+        uint32_t L = ilog2(N);
+        uint64_t *before = (uint64_t *)malloc(sizeof(uint64_t) * N);
+        uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * N);
+        for (uint32_t i = 1; i <= L; i++) {
+            uint32_t t = N / (1u << (i - 1)) + 1;
+            for (uint32_t q = 0; q < k; q++) {
+                txo_poly_auto(N, glwe_sk + (size_t)q * N, t, before);
+                for (uint32_t lev = 0; lev < p->auto_level; lev++) {
+                    uint32_t sh = 64 - p->auto_base_log * (lev + 1);
+                    for (uint32_t j = 0; j < N; j++) pt[j] = ((uint64_t)0 - before[j]) << sh;
+                    txo_glwe_encrypt(p, &rng, glwe_sk, pt, p->glwe_std,
+                                     auto_keys + ((((size_t)(i - 1) * k + q) * p->auto_level) + lev) * K * N);
+                }
+            }
+        }
+        free(before); free(pt);
+    }
+
+    /* ggsw_conv.rs:15-77: ss_key[i] = GGSW(-s_i(X)) */
+    for (uint32_t i = 0; i < k; i++) {
+        for (uint32_t j = 0; j < N; j++) m[j] = -(int64_t)glwe_sk[(size_t)i * N + j];
+        ggsw_encrypt_poly(p, &rng, glwe_sk, m, p->ss_base_log, p->ss_level, p->glwe_std,
+                          ss_key + (size_t)i * p->ss_level * K * K * N);
+    }
+    free(m);
+}
+
+/* ---------------- evaluation context ---------------- */
+txo_ctx *txo_ctx_create(const txo_params *p, const uint64_t *bsk, const uint64_t *ksk,
+                        const uint64_t *auto_keys, const uint64_t *ss_key)
+{
+    /* keep the per-call scratch buffers out of mmap/brk (they serialise OpenMP threads otherwise) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    txo_ctx *c = (txo_ctx *)calloc(1, sizeof(txo_ctx));
+    c->p = *p;
+    uint32_t N = p->N;
+    size_t nb = txo_bsk_words(p), nk = txo_ksk_words(p), na = txo_auto_words(p), ns = txo_ss_words(p);
+    c->bsk_f = (double *)malloc(sizeof(double) * nb);
+    c->ksk_f = (double *)malloc(sizeof(double) * nk);
+    c->auto_f = (double *)malloc(sizeof(double) * na * 2);
+    c->ss_f = (double *)malloc(sizeof(double) * ns);
+    /* SRV_AES:656-663 */
+    for (size_t i = 0; i < nb / N; i++) txo_fft_forward_torus_scaled(N, bsk + i * N, c->bsk_f + i * N);
+    /* SRV_AES:646-654, FftType::Vanilla */
+    for (size_t i = 0; i < nk / p->ks_N; i++)
+        txo_fft_forward_torus_scaled(p->ks_N, ksk + i * p->ks_N, c->ksk_f + i * p->ks_N);
+    /* fourier_glwe_keyswitch.rs:188-199: Split(b): lo = low b bits, hi = x >> b */
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    uint32_t sb = p->auto_split;
+    for (size_t i = 0; i < na / N; i++) {
+        for (uint32_t j = 0; j < N; j++) tmp[j] = (auto_keys[i * N + j] << (64 - sb)) >> (64 - sb);
+        txo_fft_forward_torus_scaled(N, tmp, c->auto_f + i * N);
+        for (uint32_t j = 0; j < N; j++) tmp[j] = auto_keys[i * N + j] >> sb;
+        txo_fft_forward_torus_scaled(N, tmp, c->auto_f + na + i * N);
+    }
+    free(tmp);
+    /* SRV_AES:665-687 */
+    for (size_t i = 0; i < ns / N; i++) txo_fft_forward_torus_scaled(N, ss_key + i * N, c->ss_f + i * N);
+    return c;
+}
+void txo_ctx_destroy(txo_ctx *c)
+{
+    if (!c) return;
+    free(c->bsk_f); free(c->ksk_f); free(c->auto_f); free(c->ss_f); free(c);
+}
+
+/* ---------------- Fourier pointwise MAC (fourier_poly_mult.rs:211-292) ---------------- */
+static inline void fmac(uint32_t N, double *acc, const double *d, const double *g)
+{
+    for (uint32_t j = 0; j < N; j += 2) {
+        double re = acc[j], im = acc[j + 1];
+        re = fma(d[j], g[j], re);
+        re = fma(-d[j + 1], g[j + 1], re);
+        im = fma(d[j], g[j + 1], im);
+        im = fma(d[j + 1], g[j], im);
+        acc[j] = re; acc[j + 1] = im;
+    }
+}
+
+/* out += G (x) in : tfhe fft64 add_external_product_assign restated.
+ * gF: [l][K][K] Fourier polys (level 1 first); levels are consumed finest first, rows in order. */
+void txo_extprod_add(const txo_params *p, uint64_t *out, const double *gF, const uint64_t *in,
+                     uint32_t B, uint32_t l)
+{
+    uint32_t N = p->N, K = p->k + 1;
+    double *facc = (double *)txo_tls(2, sizeof(double) * (size_t)K * N);
+    int64_t *dig = (int64_t *)txo_tls(3, sizeof(int64_t) * (size_t)l * K * N);
+    double *D = (double *)txo_tls(4, sizeof(double) * N);
+    int64_t d[16];
+    memset(facc, 0, sizeof(double) * (size_t)K * N);
+    for (uint32_t r = 0; r < K; r++)
+        for (uint32_t j = 0; j < N; j++) {
+            txo_decompose(in[(size_t)r * N + j], B, l, d);
+            for (uint32_t i = 0; i < l; i++) dig[((size_t)i * K + r) * N + j] = d[i];
+        }
+    for (uint32_t i = 0; i < l; i++) {
+        uint32_t lev = l - 1 - i;
+        for (uint32_t r = 0; r < K; r++) {
+            txo_fft_forward_int(N, dig + ((size_t)i * K + r) * N, D);
+            for (uint32_t c = 0; c < K; c++)
+                fmac(N, facc + (size_t)c * N, D, gF + (((size_t)lev * K + r) * K + c) * N);
+        }
+    }
+    for (uint32_t c = 0; c < K; c++) txo_fft_inverse_add(N, facc + (size_t)c * N, out + (size_t)c * N);
+}
+
+/* ---------------- a4: LWE key switch (fourier_glwe_keyswitch.rs:213-379, Vanilla) ---------------- */
+static void lwe_keyswitch_one(const txo_ctx *c, const uint64_t *in, uint64_t *out)
+{
+    const txo_params *p = &c->p;
+    uint32_t Nc = p->ks_N, kin = p->k * p->N / Nc, kout = p->n / Nc, Kout = kout + 1, l = p->ks_level;
+    uint64_t *g = (uint64_t *)txo_tls(14, sizeof(uint64_t) * Nc);
+    int64_t *dig = (int64_t *)txo_tls(15, sizeof(int64_t) * (size_t)l * Nc);
+    double *D = (double *)txo_tls(16, sizeof(double) * Nc);
+    double *facc = (double *)txo_tls(17, sizeof(double) * (size_t)Kout * Nc);
+    uint64_t *res = (uint64_t *)txo_tls(18, sizeof(uint64_t) * (size_t)Kout * Nc);
+    memset(facc, 0, sizeof(double) * (size_t)Kout * Nc);
+    memset(res, 0, sizeof(uint64_t) * (size_t)Kout * Nc);
+    int64_t d[16];
+    for (uint32_t q = 0; q < kin; q++) {
+        /* glwe_conv.rs:27-43 */
+        const uint64_t *a = in + (size_t)q * Nc;
+        g[0] = a[0];
+        for (uint32_t j = 1; j < Nc; j++) g[j] = (uint64_t)0 - a[Nc - j];
+        for (uint32_t j = 0; j < Nc; j++) {
+            txo_decompose(g[j], p->ks_base_log, l, d);
+            for (uint32_t i = 0; i < l; i++) dig[(size_t)i * Nc + j] = d[i];
+        }
+        for (uint32_t i = 0; i < l; i++) {
+            uint32_t lev = l - 1 - i;
+            txo_fft_forward_int(Nc, dig + (size_t)i * Nc, D);
+            for (uint32_t cc = 0; cc < Kout; cc++)
+                fmac(Nc, facc + (size_t)cc * Nc, D, c->ksk_f + (((size_t)q * l + lev) * Kout + cc) * Nc);
+        }
+    }
+    res[(size_t)kout * Nc] = in[(size_t)p->k * p->N];
+    for (uint32_t cc = 0; cc < Kout; cc++) txo_fft_inverse_add(Nc, facc + (size_t)cc * Nc, res + (size_t)cc * Nc);
+    /* sample extract at 0 */
+    for (uint32_t q = 0; q < kout; q++) {
+        out[(size_t)q * Nc] = res[(size_t)q * Nc];
+        for (uint32_t j = 1; j < Nc; j++) out[(size_t)q * Nc + j] = (uint64_t)0 - res[(size_t)q * Nc + Nc - j];
+    }
+    out[p->n] = res[(size_t)kout * Nc];
+}
+void txo_lwe_keyswitch(const txo_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
+{
+    size_t big = (size_t)c->p.k * c->p.N + 1, small = c->p.n + 1;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t i = 0; i < count; i++) lwe_keyswitch_one(c, in + i * big, out + i * small);
+}
+
+/* ---------------- a5: blind rotation (ggsw_conv.rs:250-300, pbs.rs:70-146) ---------------- */
+static void blind_rotate_one(const txo_ctx *c, const uint64_t *lwe, uint64_t *acc)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, k = p->k, K = k + 1, n = p->n, lg = ilog2(N);
+    uint32_t lut_count = 1u << p->log_lut_count;
+    uint64_t *tv = (uint64_t *)txo_tls(5, sizeof(uint64_t) * N);
+    uint64_t *ct1 = (uint64_t *)txo_tls(6, sizeof(uint64_t) * (size_t)K * N);
+    /* ggsw_conv.rs:252-261 (single accumulator: lut_count >= cbs_level):
+     * orig[i] = -1 << (log_scale_i - 1); negate i < N/2; rotate left by N/2 */
+    {
+        uint64_t *o = (uint64_t *)txo_tls(7, sizeof(uint64_t) * N);
+        for (uint32_t i = 0; i < N; i++) {
+            uint32_t kk = i % lut_count;
+            uint32_t log_scale = 64 - (kk + 1) * p->cbs_base_log;
+            uint64_t v = ((uint64_t)0 - (uint64_t)1) << (log_scale - 1);
+            o[i] = (i < N / 2) ? (uint64_t)0 - v : v;
+        }
+        for (uint32_t j = 0; j < N; j++) tv[j] = o[(j + N / 2) % N];
+    }
+    memset(acc, 0, sizeof(uint64_t) * (size_t)K * N);
+    /* pbs.rs:84-101: acc = TV * X^(-b~) */
+    uint32_t bt = txo_modswitch(lwe[n], lg, p->log_lut_count);
+    txo_poly_rotate(N, tv, -(int64_t)bt, acc + (size_t)k * N);
+    for (uint32_t i = 0; i < n; i++) {
+        if (lwe[i] == 0) continue;                       /* pbs.rs:111 */
+        uint32_t at = txo_modswitch(lwe[i], lg, p->log_lut_count);
+        for (uint32_t q = 0; q < K; q++) {               /* pbs.rs:125-134 */
+            txo_poly_rotate(N, acc + (size_t)q * N, at, ct1 + (size_t)q * N);
+            for (uint32_t j = 0; j < N; j++) ct1[(size_t)q * N + j] -= acc[(size_t)q * N + j];
+        }
+        txo_extprod_add(p, acc, c->bsk_f + (size_t)i * p->pbs_level * K * K * N, ct1,
+                        p->pbs_base_log, p->pbs_level);
+    }
+}
+void txo_blind_rotate(const txo_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
+{
+    size_t small = c->p.n + 1, gl = (size_t)(c->p.k + 1) * c->p.N;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t i = 0; i < count; i++) blind_rotate_one(c, in + i * small, out + i * gl);
+}
+
+/* ---------------- a7: trace (automorphism.rs:134-149, 205-233; fourier_glwe_keyswitch.rs:213-342) ---------------- */
+static void auto_keyswitch_add(const txo_ctx *c, uint32_t idx /* i-1 */, uint64_t *ct)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, k = p->k, K = k + 1, l = p->auto_level;
+    uint32_t t = N / (1u << idx) + 1;
+    size_t na = txo_auto_words(p);
+    uint64_t *pw = (uint64_t *)txo_tls(8, sizeof(uint64_t) * (size_t)K * N);
+    int64_t *dig = (int64_t *)txo_tls(9, sizeof(int64_t) * (size_t)l * N);
+    double *D = (double *)txo_tls(10, sizeof(double) * (size_t)l * N);
+    double *facc = (double *)txo_tls(11, sizeof(double) * (size_t)2 * K * N);
+    uint64_t *buf = (uint64_t *)txo_tls(12, sizeof(uint64_t) * (size_t)K * N);
+    int64_t d[16];
+    memset(facc, 0, sizeof(double) * (size_t)2 * K * N);
+    memset(buf, 0, sizeof(uint64_t) * (size_t)K * N);
+    for (uint32_t q = 0; q < K; q++) txo_poly_auto(N, ct + (size_t)q * N, t, pw + (size_t)q * N);
+    for (uint32_t q = 0; q < k; q++) {
+        for (uint32_t j = 0; j < N; j++) {
+            txo_decompose(pw[(size_t)q * N + j], p->auto_base_log, l, d);
+            for (uint32_t i = 0; i < l; i++) dig[(size_t)i * N + j] = d[i];
+        }
+        for (uint32_t i = 0; i < l; i++) txo_fft_forward_int(N, dig + (size_t)i * N, D + (size_t)i * N);
+        for (uint32_t s = 0; s < 2; s++)
+            for (uint32_t i = 0; i < l; i++) {
+                uint32_t lev = l - 1 - i;
+                const double *key = c->auto_f + s * na + ((((size_t)idx * k + q) * l) + lev) * K * N;
+                for (uint32_t cc = 0; cc < K; cc++)
+                    fmac(N, facc + ((size_t)s * K + cc) * N, D + (size_t)i * N, key + (size_t)cc * N);
+            }
+    }
+    /* keyswitch output = (0,..,0, body of the permuted input) + lo + 2^split * hi */
+    memcpy(buf + (size_t)k * N, pw + (size_t)k * N, sizeof(uint64_t) * N);
+    for (uint32_t cc = 0; cc < K; cc++) txo_fft_inverse_add(N, facc + (size_t)cc * N, buf + (size_t)cc * N);
+    {
+        uint64_t *hi = (uint64_t *)txo_tls(13, sizeof(uint64_t) * (size_t)K * N);
+        memset(hi, 0, sizeof(uint64_t) * (size_t)K * N);
+        for (uint32_t cc = 0; cc < K; cc++) txo_fft_inverse_add(N, facc + ((size_t)K + cc) * N, hi + (size_t)cc * N);
+        for (size_t j = 0; j < (size_t)K * N; j++) buf[j] += hi[j] << p->auto_split;
+    }
+    for (size_t j = 0; j < (size_t)K * N; j++) ct[j] += buf[j];       /* automorphism.rs:229 */
+}
+static void trace_one(const txo_ctx *c, uint64_t *ct)
+{
+    uint32_t L = ilog2(c->p.N);
+    for (uint32_t i = 0; i < L; i++) auto_keyswitch_add(c, i, ct);
+}
+void txo_trace(const txo_ctx *c, uint64_t *glwe, size_t count)
+{
+    size_t gl = (size_t)(c->p.k + 1) * c->p.N;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t i = 0; i < count; i++) trace_one(c, glwe + i * gl);
+}
+
+/* ---------------- a6: multi-value extract + preprocessing + LWE->GLWE const (ggsw_conv.rs:304-316) ---------------- */
+static void extract_level(const txo_ctx *c, const uint64_t *acc, uint32_t lvl /* 1-based */, uint64_t *glwe)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, k = p->k, K = k + 1, lgN = ilog2(N);
+    uint32_t kk = lvl - 1;
+    uint32_t log_scale = 64 - lvl * p->cbs_base_log;
+    uint64_t *buf = (uint64_t *)txo_tls(19, sizeof(uint64_t) * (size_t)K * N);
+    uint64_t *lwe = (uint64_t *)txo_tls(20, sizeof(uint64_t) * ((size_t)k * N + 1));
+    for (uint32_t q = 0; q < K; q++) txo_poly_rotate(N, acc + (size_t)q * N, -(int64_t)kk, buf + (size_t)q * N);
+    buf[(size_t)k * N] += (uint64_t)1 << (log_scale - 1);
+    txo_sample_extract(p, buf, 0, lwe);
+    /* mod_switch.rs:20-25,46-49,67-73: x -> (x - x mod 2^log2N) / 2^log2N */
+    for (size_t j = 0; j <= (size_t)k * N; j++) lwe[j] = (lwe[j] - (lwe[j] & (((uint64_t)1 << lgN) - 1))) >> lgN;
+    /* glwe_conv.rs:27-43 */
+    memset(glwe, 0, sizeof(uint64_t) * (size_t)K * N);
+    glwe[(size_t)k * N] = lwe[(size_t)k * N];
+    for (uint32_t q = 0; q < k; q++) {
+        const uint64_t *a = lwe + (size_t)q * N;
+        uint64_t *g = glwe + (size_t)q * N;
+        g[0] = a[0];
+        for (uint32_t j = 1; j < N; j++) g[j] = (uint64_t)0 - a[N - j];
+    }
+}
+void txo_extract_trace(const txo_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
+{
+    size_t gl = (size_t)(c->p.k + 1) * c->p.N;
+    uint32_t L = c->p.cbs_level;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t i = 0; i < count * L; i++) {
+        size_t ct = i / L; uint32_t lv = (uint32_t)(i % L);
+        uint64_t *g = glev + (ct * L + lv) * gl;
+        extract_level(c, acc + ct * gl, lv + 1, g);
+        trace_one(c, g);
+    }
+}
+
+/* ---------------- a8: scheme switching (ggsw_conv.rs:163-193) ---------------- */
+void txo_scheme_switch(const txo_ctx *c, const uint64_t *glev, size_t count, uint64_t *ggsw)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, k = p->k, K = k + 1, L = p->cbs_level;
+    size_t gl = (size_t)K * N;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t i = 0; i < count * L; i++) {
+        const uint64_t *g = glev + i * gl;
+        uint64_t *rows = ggsw + i * K * gl;
+        memset(rows, 0, sizeof(uint64_t) * K * gl);
+        for (uint32_t r = 0; r < k; r++)
+            txo_extprod_add(p, rows + (size_t)r * gl, c->ss_f + (size_t)r * p->ss_level * K * gl, g,
+                            p->ss_base_log, p->ss_level);
+        memcpy(rows + (size_t)k * gl, g, sizeof(uint64_t) * gl);
+    }
+}
+
+/* ---------------- a9 ---------------- */
+void txo_ggsw_to_fourier(const txo_ctx *c, const uint64_t *ggsw, size_t count, double *ggsw_f)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, K = p->k + 1;
+    size_t polys = count * p->cbs_level * K * K;
+    #pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (size_t i = 0; i < polys; i++) txo_fft_forward_torus_scaled(N, ggsw + i * N, ggsw_f + i * N);
+}
+
+/* ---------------- a10: LUT CMux tree (SRV_AES:550-588) ---------------- */
+void txo_lut_eval(const txo_ctx *c, const double *ggsw_f, size_t nbytes, const uint64_t *luts,
+                  size_t nlut, size_t lut_stride_byte, size_t lut_stride_set, uint64_t *out)
+{
+    const txo_params *p = &c->p;
+    uint32_t N = p->N, k = p->k, K = k + 1, L = p->cbs_level;
+    size_t gl = (size_t)K * N, big = (size_t)k * N + 1;
+    size_t ggsw_sz = (size_t)L * K * gl;           /* doubles per Fourier GGSW */
+    uint32_t num_par = N / 256;
+    #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+    for (size_t w = 0; w < nbytes * nlut * 2; w++) {
+        size_t byte = w / (nlut * 2), set = (w / 2) % nlut; uint32_t acc_idx = (uint32_t)(w % 2);
+        uint64_t *acc = (uint64_t *)txo_tls(21, sizeof(uint64_t) * gl);
+        uint64_t *buf = (uint64_t *)txo_tls(22, sizeof(uint64_t) * gl);
+        memcpy(acc, luts + (byte % 16) * lut_stride_byte + set * lut_stride_set + (size_t)acc_idx * gl, sizeof(uint64_t) * gl);
+        for (uint32_t i = 0; i < 8; i++) {
+            for (uint32_t q = 0; q < K; q++) {
+                txo_poly_rotate(N, acc + (size_t)q * N, -(int64_t)(1u << i), buf + (size_t)q * N);
+                for (uint32_t j = 0; j < N; j++) buf[(size_t)q * N + j] -= acc[(size_t)q * N + j];
+            }
+            txo_extprod_add(p, acc, ggsw_f + (byte * 8 + i) * ggsw_sz, buf, p->cbs_base_log, L);
+        }
+        for (uint32_t i = 0; i < num_par; i++) {
+            uint32_t bit = acc_idx * num_par + i;
+            txo_sample_extract(p, acc, i * 256, out + ((set * nbytes + byte) * 8 + bit) * big);
+        }
+    }
+}
+
+void txo_circuit_bootstrap(const txo_ctx *c, const uint64_t *lwe_big, size_t count, double *ggsw_f)
+{
+    const txo_params *p = &c->p;
+    size_t K = p->k + 1, gl = K * p->N, L = p->cbs_level;
+    uint64_t *small = (uint64_t *)malloc(sizeof(uint64_t) * count * (p->n + 1));
+    uint64_t *acc = (uint64_t *)malloc(sizeof(uint64_t) * count * gl);
+    uint64_t *glev = (uint64_t *)malloc(sizeof(uint64_t) * count * L * gl);
+    uint64_t *ggsw = (uint64_t *)malloc(sizeof(uint64_t) * count * L * K * gl);
+    txo_lwe_keyswitch(c, lwe_big, count, small);
+    txo_blind_rotate(c, small, count, acc);
+    txo_extract_trace(c, acc, count, glev);
+    txo_scheme_switch(c, glev, count, ggsw);
+    txo_ggsw_to_fourier(c, ggsw, count, ggsw_f);
+    free(small); free(acc); free(glev); free(ggsw);
+}
