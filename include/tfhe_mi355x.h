@@ -1,0 +1,121 @@
+/*
+ * tfhe_mi355x.h -- C ABI of the MI355X-native AES-under-TFHE transciphering engine
+ * (libtfhe_mi355x.so, built from temp-fhe-transciphering_amd/csrc for gfx950).
+ *
+ * The reference (code-perspective/temp-fhe-transciphering) has no FFI: its only boundary is the
+ * process-level stage contract of harness/run_submission.py:68-115.  This ABI is the in-process
+ * boundary the reference's stage executables would bind if their hot path were offloaded; each
+ * entry point names the reference interface it replaces.  Plain pointers and sizes only, no C++
+ * or torch types; return value 0 = success, negative = error (tx_last_error() has the text);
+ * no exception crosses the boundary.  One context per GPU; calls on one context must be
+ * serialised by the caller (the reference is single-threaded, submission/cbs_lib/Cargo.toml:31-34).
+ *
+ * All ciphertext and key material at the boundary is the reference's standard domain:
+ * unsigned 64-bit torus words (q = 2^64), layouts given below.  Fourier-domain forms are private.
+ */
+#ifndef TFHE_MI355X_H
+#define TFHE_MI355X_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors `AesParam<u64>` (submission/cbs_lib/src/aes_params.rs:4-27); the values in use are
+ * `AES_TIGHT` (submission/cbs_lib/src/aes_instances.rs:76-97).  The HIP kernels are specialised
+ * for N = 1024, k = 2 and the AES_TIGHT decomposition constants; `n` (a multiple of 256, at most
+ * 1024) is a run-time value.  tx_create() rejects anything else. */
+typedef struct {
+    uint32_t n, N, k;
+    uint32_t pbs_base_log, pbs_level;
+    uint32_t ks_base_log, ks_level, ks_N;
+    uint32_t auto_base_log, auto_level, auto_split;
+    uint32_t ss_base_log, ss_level;
+    uint32_t cbs_base_log, cbs_level;
+    uint32_t log_lut_count;
+    double   lwe_std, glwe_std;          /* only used by the client side */
+} tx_params;
+
+typedef struct tx_ctx tx_ctx;
+
+/* `&*AES_TIGHT` (server_encrypted_aes_decryption.rs:637) */
+void tx_params_aes_tight(tx_params *p);
+
+const char *tx_last_error(void);
+
+/* Replaces the key-conversion prologue of `main` (server_encrypted_aes_decryption.rs:640-687):
+ * creates a context on HIP device `device`. */
+tx_ctx *tx_create(const tx_params *p, int device);
+void    tx_destroy(tx_ctx *c);
+
+/* Standard-domain evaluation keys (host pointers), transformed once on the GPU and kept resident:
+ *   bsk       LweBootstrapKeyOwned<u64>      [n][pbs_level][K][K][N]         (bsk.bin,  :630)
+ *   ksk       GlweKeyswitchKeyOwned<u64>     [kN/ks_N][ks_level][n/ks_N+1][ks_N]  (ksk.bin, :631)
+ *   auto_keys standard-domain GLWE key-switch keys for t = N/2^(i-1)+1, i = 1..log2 N:
+ *             [log2 N][k][auto_level][K][N]  (auto_keys.bin :633-643 holds their Fourier form)
+ *   ss_key    GgswCiphertextListOwned<u64>   [k][ss_level][K][K][N]          (ss_key.bin, :632)
+ * levels are stored level 1 (coarsest) first, as tfhe-rs does. K = k + 1. */
+int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, const uint64_t *ksk,
+                      const uint64_t *auto_keys, const uint64_t *ss_key);
+
+/* `AllRdKeys` (submission/src/data_struct.rs:10-26; trans_key.bin, SRV_AES :635) as one blob:
+ * [set 0..8][mult x9,x11,x13,x14][byte 16][acc 2][K][N] then round 0 [byte 16][acc 2][K][N];
+ * set 0 = fused rounds 10/9, sets 1..8 = rounds 8..1.  words = (9*4+1)*16*2*K*N. */
+int tx_load_round_luts(tx_ctx *c, const uint64_t *luts, size_t words);
+
+/* Forward-cipher tables for CTR mode (harness sizes >= 1, aes_keygen_and_encrypt.py:49-55; the
+ * reference bins do not implement it, building blocks cbs_lib/src/aes_he.rs:686-786):
+ * [set 0..9][mult x1,x2,x3][byte 16][acc 2][K][N]; words = 10*3*16*2*K*N. */
+int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words);
+
+/* Replaces `aes_to_lwe_trasnciphering` (server_encrypted_aes_decryption.rs:28-191), batched over
+ * n_blocks independent 16-byte AES blocks.  iv == NULL: the reference's ECB inverse-cipher
+ * schedule; iv != NULL: CTR mode on counter blocks iv + i.  out_lwe: n_blocks*128 LWE
+ * ciphertexts of kN+1 words, bit order MSB first inside each byte (:182-189).
+ * out_is_device != 0: out_lwe is a device pointer on the context's GPU (result stays in HBM). */
+int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
+                   uint64_t *out_lwe, int out_is_device);
+
+/* Same schedule stopped after `rounds_done` bootstrapped rounds (0..9), state returned in the
+ * reference's internal order (LSB first); used by the parity tests only. */
+int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, int rounds_done,
+                           uint64_t *out_state);
+
+/* Replaces the body of `main` in server_encrypted_compute.rs:203-356 (max of n_values 16-bit
+ * values given as n_values*16 LWE bits, MSB first); log-depth tournament.
+ * out: 16 LWE ciphertexts. */
+int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe);
+
+/* ---- stage-level entry points (one per row of SURVEY.md section 8a), host pointers ---- */
+/* a4 keyswitch_lwe_ciphertext_by_glwe_keyswitch (fourier_glwe_keyswitch.rs:344-379) */
+int tx_stage_lwe_keyswitch(tx_ctx *c, const uint64_t *lwe_big, size_t count, uint64_t *lwe_small);
+/* a5 gen_blind_rotate_local_assign on the CBS test vector (pbs.rs:70-161, ggsw_conv.rs:250-300) */
+int tx_stage_blind_rotate(tx_ctx *c, const uint64_t *lwe_small, size_t count, uint64_t *acc);
+/* a6+a7 extract / preprocess / LWE->GLWE / trace_assign (ggsw_conv.rs:304-316) -> GLev */
+int tx_stage_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev);
+/* a8+a9 switch_scheme + convert_standard_ggsw_ciphertext_to_fourier (ggsw_conv.rs:163-193,
+ * SRV_AES:430-436); output is the private Fourier layout, count*cbs_level*K*K*N doubles */
+int tx_stage_scheme_switch_fourier(tx_ctx *c, const uint64_t *glev, size_t count, double *ggsw_f);
+/* a10 evaluate_8_to_8_cipher_lut (SRV_AES:550-588) for nlut tables of loaded set `set`
+ * (ctr == 0: round tables, nlut = 4 or 1 for set 9; ctr != 0: CTR tables).
+ * out[(lut*nbytes + byte)*8 + bit] big LWEs */
+int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes, int ctr, int set, int nlut,
+                      uint64_t *out);
+
+/* ---- measurement ---- */
+/* HIP-event time (ms) spent in each kernel family during the last tx_transcipher / tx_max_u16
+ * call, measured on the stream the kernels were launched on, and the number of launches. */
+typedef struct {
+    double ms_keyswitch, ms_blind_rotate, ms_trace, ms_scheme_switch, ms_lut_eval, ms_linear, ms_total;
+    uint32_t n_keyswitch, n_blind_rotate, n_trace, n_scheme_switch, n_lut_eval, n_linear;
+} tx_timing;
+int tx_get_timing(tx_ctx *c, tx_timing *t);
+
+/* the forward-transform twiddle table [22][64] complex used by the kernels (for table pinning) */
+int tx_get_twiddles(tx_ctx *c, double *out /* 22*64*2 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

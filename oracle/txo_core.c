@@ -388,14 +388,16 @@ void txo_extprod_add(const txo_params *p, uint64_t *out, const double *gF, const
             txo_decompose(in[(size_t)r * N + j], B, l, d);
             for (uint32_t i = 0; i < l; i++) dig[((size_t)i * K + r) * N + j] = d[i];
         }
-    for (uint32_t i = 0; i < l; i++) {
-        uint32_t lev = l - 1 - i;
-        for (uint32_t r = 0; r < K; r++) {
+    /* summation order of the f64 accumulators: row outer, level (finest first) inner, as the HIP
+     * kernels do.  tfhe-rs nests level outer / row inner; the sums are mathematically equal and the
+     * reference's own rounding is not reproducible here anyway (concrete-fft is absent). */
+    for (uint32_t r = 0; r < K; r++)
+        for (uint32_t i = 0; i < l; i++) {
+            uint32_t lev = l - 1 - i;
             txo_fft_forward_int(N, dig + ((size_t)i * K + r) * N, D);
             for (uint32_t c = 0; c < K; c++)
                 fmac(N, facc + (size_t)c * N, D, gF + (((size_t)lev * K + r) * K + c) * N);
         }
-    }
     for (uint32_t c = 0; c < K; c++) txo_fft_inverse_add(N, facc + (size_t)c * N, out + (size_t)c * N);
 }
 

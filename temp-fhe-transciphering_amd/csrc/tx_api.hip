@@ -1,0 +1,572 @@
+// tx_api.hip -- C ABI (include/tfhe_mi355x.h) over the gfx950 kernels: context, key residency,
+// the AES round schedules and the max tournament.  Host logic mirrors the reference's
+// `main` / `aes_to_lwe_trasnciphering` (server_encrypted_aes_decryption.rs:28-191, 599-707) and
+// server_encrypted_compute.rs:203-356; all arithmetic on ciphertexts runs in the kernels of
+// tx_kernels.hpp.  There is no CPU fallback: every entry point fails if HIP does.
+#include "../../include/tfhe_mi355x.h"
+#include "tx_kernels.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace txd;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return -1; }
+extern "C" const char *tx_last_error(void) { return g_err.c_str(); }
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+enum Family { F_KS = 0, F_BR, F_TRACE, F_SS, F_LUT, F_LIN, F_COUNT };
+
+struct tx_ctx {
+    tx_params p;
+    int device;
+    hipStream_t stream;
+    // resident evaluation keys (Fourier, private layout)
+    cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
+    size_t auto_split_stride = 0;
+    cplx *tw = nullptr, *tw256 = nullptr;
+    uint64_t *luts = nullptr, *ctr_luts = nullptr;
+    bool have_keys = false;
+    // workspace (grown on demand)
+    size_t ws_blocks = 0;
+    uint64_t *st = nullptr, *sm = nullptr, *small = nullptr, *acc = nullptr, *glev = nullptr, *res = nullptr;
+    cplx *ggsw_f = nullptr;
+    uint8_t *d_bytes = nullptr, *d_ct = nullptr;
+    // timing
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    tx_timing timing;
+    bool time_enabled = true;
+};
+
+extern "C" void tx_params_aes_tight(tx_params *p)
+{   // cbs_lib/src/aes_instances.rs:76-97
+    p->n = 768; p->N = 1024; p->k = 2;
+    p->pbs_base_log = 23; p->pbs_level = 1;
+    p->ks_base_log = 4; p->ks_level = 3; p->ks_N = 256;
+    p->auto_base_log = 13; p->auto_level = 3; p->auto_split = 41;
+    p->ss_base_log = 17; p->ss_level = 2;
+    p->cbs_base_log = 2; p->cbs_level = 7;
+    p->log_lut_count = 3;
+    p->lwe_std = 0.00000702047462940120;
+    p->glwe_std = 0.00000000000000029403601535432533;
+}
+
+static cplx unit_root(long double num, long double den)
+{   // exp(i pi num / den), rounded once from long double
+    const long double PI = 3.14159265358979323846264338327950288L;
+    long double a = PI * num / den;
+    return make_double2((double)cosl(a), (double)sinl(a));
+}
+
+static int upload_tables(tx_ctx *c)
+{
+    std::vector<cplx> tw(TW_ROWS * 64), t2(192);
+    for (int m = 0; m < 8; m++)
+        for (int t = 0; t < 64; t++) tw[m * 64 + t] = unit_root(t + 64 * m, 1024);
+    for (int r = 1; r < 8; r++)
+        for (int t = 0; t < 64; t++) tw[(7 + r) * 64 + t] = unit_root(2 * (t * r), 512);
+    for (int r = 1; r < 8; r++)
+        for (int t = 0; t < 64; t++) tw[(14 + r) * 64 + t] = unit_root(2 * ((t & 7) * r), 64);
+    for (int j = 0; j < 128; j++) t2[j] = unit_root(j, 256);
+    for (int j = 0; j < 64; j++) t2[128 + j] = unit_root(2 * j, 128);
+    HIP_OK(hipMalloc(&c->tw, tw.size() * sizeof(cplx)));
+    HIP_OK(hipMalloc(&c->tw256, t2.size() * sizeof(cplx)));
+    HIP_OK(hipMemcpy(c->tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(c->tw256, t2.data(), t2.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" tx_ctx *tx_create(const tx_params *p, int device)
+{
+    tx_params ref; tx_params_aes_tight(&ref);
+    if (p->N != (uint32_t)N || p->k != 2 || p->pbs_base_log != PBS_B || p->pbs_level != PBS_L ||
+        p->ks_base_log != KS_B || p->ks_level != KS_L || p->ks_N != KS_N || p->auto_base_log != AUTO_B ||
+        p->auto_level != AUTO_L || p->auto_split != AUTO_SPLIT || p->ss_base_log != SS_B || p->ss_level != SS_L ||
+        p->cbs_base_log != CBS_B || p->cbs_level != CBS_L || p->log_lut_count != LOG_LUT) {
+        fail("tx_create: kernels are specialised for the AES_TIGHT constants (only n may differ)");
+        return nullptr;
+    }
+    if (p->n == 0 || p->n % KS_N != 0 || p->n > 1024) { fail("tx_create: n must be a multiple of 256, at most 1024"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { fail("tx_create: no such HIP device (the HIP path is mandatory, there is no CPU fallback)"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail("tx_create: hipSetDevice failed"); return nullptr; }
+    tx_ctx *c = new tx_ctx();
+    c->p = *p; c->device = device;
+    memset(&c->timing, 0, sizeof c->timing);
+    if (hipStreamCreate(&c->stream) != hipSuccess) { fail("tx_create: hipStreamCreate failed"); delete c; return nullptr; }
+    if (upload_tables(c) != 0) { delete c; return nullptr; }
+    return c;
+}
+
+static void free_ws(tx_ctx *c)
+{
+    hipFree(c->st); hipFree(c->sm); hipFree(c->small); hipFree(c->acc); hipFree(c->glev); hipFree(c->res);
+    hipFree(c->ggsw_f); hipFree(c->d_bytes); hipFree(c->d_ct);
+    c->st = c->sm = c->small = c->acc = c->glev = c->res = nullptr; c->ggsw_f = nullptr; c->d_bytes = c->d_ct = nullptr;
+    c->ws_blocks = 0;
+}
+
+extern "C" void tx_destroy(tx_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_ws(c);
+    hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
+    hipFree(c->tw); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
+    for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- sizes ----
+static size_t bsk_words(const tx_params &p) { return (size_t)p.n * PBS_L * KP * KP * N; }
+static size_t ksk_words(const tx_params &p) { return (size_t)(2 * N / KS_N) * KS_L * (p.n / KS_N + 1) * KS_N; }
+static size_t auto_words() { return (size_t)LOGN * 2 * AUTO_L * KP * N; }
+static size_t ss_words() { return (size_t)2 * SS_L * KP * KP * N; }
+static size_t lut_words() { return (size_t)(9 * 4 + 1) * 16 * 2 * GL; }
+static size_t ctr_lut_words() { return (size_t)10 * 3 * 16 * 2 * GL; }
+
+static inline int grid_for(size_t units) { return (int)((units + WAVES - 1) / WAVES); }
+
+// ---- timing helpers: HIP events on the launch stream ----
+static void ev_begin(tx_ctx *c, int fam)
+{
+    if (!c->time_enabled) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        c->ev_pool.push_back({a, b});
+    }
+    auto &e = c->ev_pool[c->ev_used];
+    hipEventRecord(e.first, c->stream);
+    c->evs.push_back({fam, e});
+}
+static void ev_end(tx_ctx *c)
+{
+    if (!c->time_enabled) return;
+    hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    c->ev_used++;
+}
+static void timing_reset(tx_ctx *c) { c->evs.clear(); c->ev_used = 0; memset(&c->timing, 0, sizeof c->timing); }
+static void timing_collect(tx_ctx *c)
+{
+    double ms[F_COUNT] = {0}; uint32_t cnt[F_COUNT] = {0};
+    for (auto &e : c->evs) {
+        float t = 0; hipEventElapsedTime(&t, e.second.first, e.second.second);
+        ms[e.first] += t; cnt[e.first]++;
+    }
+    tx_timing &t = c->timing;
+    t.ms_keyswitch = ms[F_KS]; t.ms_blind_rotate = ms[F_BR]; t.ms_trace = ms[F_TRACE];
+    t.ms_scheme_switch = ms[F_SS]; t.ms_lut_eval = ms[F_LUT]; t.ms_linear = ms[F_LIN];
+    t.n_keyswitch = cnt[F_KS]; t.n_blind_rotate = cnt[F_BR]; t.n_trace = cnt[F_TRACE];
+    t.n_scheme_switch = cnt[F_SS]; t.n_lut_eval = cnt[F_LUT]; t.n_linear = cnt[F_LIN];
+    t.ms_total = 0; for (int i = 0; i < F_COUNT; i++) t.ms_total += ms[i];
+}
+extern "C" int tx_get_timing(tx_ctx *c, tx_timing *t) { if (!c || !t) return fail("tx_get_timing: null"); *t = c->timing; return 0; }
+extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
+{
+    if (!c || !out) return fail("tx_get_twiddles: null");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpy(out, c->tw, TW_ROWS * 64 * sizeof(cplx), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- key loading (SRV_AES:640-687) ----
+static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst, int mode)
+{
+    uint64_t *tmp = nullptr;
+    HIP_OK(hipMalloc(&tmp, words * 8));
+    HIP_OK(hipMemcpyAsync(tmp, h_src, words * 8, hipMemcpyHostToDevice, c->stream));
+    int npoly = (int)(words / N);
+    hipLaunchKernelGGL(k_fwd_torus, dim3(grid_for(npoly)), dim3(256), LDS_BYTES, c->stream, tmp, d_dst, npoly, mode,
+                       (int)AUTO_SPLIT, c->tw);
+    if (mode == 1) {   // both halves of the split key from one upload
+        hipLaunchKernelGGL(k_fwd_torus, dim3(grid_for(npoly)), dim3(256), LDS_BYTES, c->stream, tmp,
+                           d_dst + c->auto_split_stride, npoly, 2, (int)AUTO_SPLIT, c->tw);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipFree(tmp));
+    return 0;
+}
+
+extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, const uint64_t *ksk, const uint64_t *auto_keys,
+                                 const uint64_t *ss_key)
+{
+    if (!c || !bsk || !ksk || !auto_keys || !ss_key) return fail("tx_load_eval_keys: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
+    c->bsk_f = c->ksk_f = c->auto_f = c->ss_f = nullptr; c->have_keys = false;
+    const size_t nb = bsk_words(c->p), nk = ksk_words(c->p), na = auto_words(), ns = ss_words();
+    HIP_OK(hipMalloc(&c->bsk_f, nb * 8));
+    HIP_OK(hipMalloc(&c->ksk_f, nk * 8));
+    HIP_OK(hipMalloc(&c->auto_f, na * 8 * 2));
+    HIP_OK(hipMalloc(&c->ss_f, ns * 8));
+    c->auto_split_stride = na / 2;                                  // complex units per split
+    if (fwd_polys(c, bsk, nb, c->bsk_f, 0)) return -1;
+    if (fwd_polys(c, auto_keys, na, c->auto_f, 1)) return -1;
+    if (fwd_polys(c, ss_key, ns, c->ss_f, 0)) return -1;
+    {
+        uint64_t *tmp = nullptr;
+        HIP_OK(hipMalloc(&tmp, nk * 8));
+        HIP_OK(hipMemcpyAsync(tmp, ksk, nk * 8, hipMemcpyHostToDevice, c->stream));
+        int npoly = (int)(nk / KS_N);
+        hipLaunchKernelGGL(k_fwd_torus256, dim3(grid_for(npoly)), dim3(256), 0, c->stream, tmp, c->ksk_f, npoly, c->tw256);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipFree(tmp));
+    }
+    c->have_keys = true;
+    return 0;
+}
+
+static int load_blob(tx_ctx *c, uint64_t **dst, const uint64_t *src, size_t words, size_t expect, const char *what)
+{
+    if (!c || !src) return fail(std::string(what) + ": null argument");
+    if (words != expect) return fail(std::string(what) + ": wrong size");
+    HIP_OK(hipSetDevice(c->device));
+    hipFree(*dst); *dst = nullptr;
+    HIP_OK(hipMalloc(dst, words * 8));
+    HIP_OK(hipMemcpy(*dst, src, words * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int tx_load_round_luts(tx_ctx *c, const uint64_t *luts, size_t words)
+{ return load_blob(c, c ? &c->luts : nullptr, luts, words, lut_words(), "tx_load_round_luts"); }
+extern "C" int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words)
+{ return load_blob(c, c ? &c->ctr_luts : nullptr, luts, words, ctr_lut_words(), "tx_load_ctr_luts"); }
+
+// ---- workspace ----
+static int ensure_ws(tx_ctx *c, size_t nb)
+{
+    if (nb <= c->ws_blocks) return 0;
+    free_ws(c);
+    const size_t bits = nb * 128;
+    HIP_OK(hipMalloc(&c->st, bits * BIG * 8));
+    HIP_OK(hipMalloc(&c->res, bits * BIG * 8));
+    HIP_OK(hipMalloc(&c->sm, 4 * bits * BIG * 8));
+    HIP_OK(hipMalloc(&c->small, bits * (c->p.n + 1) * 8));
+    HIP_OK(hipMalloc(&c->acc, bits * GL * 8));
+    HIP_OK(hipMalloc(&c->glev, bits * CBS_L * GL * 8));
+    HIP_OK(hipMalloc(&c->ggsw_f, bits * CBS_L * KP * KP * H * sizeof(cplx)));
+    HIP_OK(hipMalloc(&c->d_bytes, nb * 16));
+    HIP_OK(hipMalloc(&c->d_ct, nb * 16));
+    c->ws_blocks = nb;
+    return 0;
+}
+
+// ---- kernel launch wrappers (device pointers) ----
+static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
+{
+    ev_begin(c, F_KS);
+    hipLaunchKernelGGL(k_lwe_keyswitch, dim3(grid_for(count)), dim3(256), 0, c->stream, in, out, (int)count, (int)c->p.n,
+                       c->ksk_f, c->tw256);
+    ev_end(c);
+}
+static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
+{
+    ev_begin(c, F_BR);
+    hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES, c->stream, in, acc, (int)count,
+                       (int)c->p.n, c->bsk_f, c->tw);
+    ev_end(c);
+}
+static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
+{
+    ev_begin(c, F_TRACE);
+    hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, acc, glev,
+                       (int)count, c->auto_f, c->auto_split_stride, c->tw);
+    ev_end(c);
+}
+static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
+{
+    ev_begin(c, F_SS);
+    hipLaunchKernelGGL(k_scheme_switch, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, glev, ggsw_f,
+                       (int)(count * CBS_L), c->ss_f, c->tw);
+    ev_end(c);
+}
+static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t *lut_set, size_t lut_stride, int nlut,
+                    uint64_t *out)
+{
+    ev_begin(c, F_LUT);
+    hipLaunchKernelGGL(k_lut_eval, dim3(grid_for(nbytes * nlut * 2)), dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
+                       lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw);
+    ev_end(c);
+}
+// KS + CBS of `count` big LWEs into Fourier GGSWs
+static void run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw_f)
+{
+    run_ks(c, lwe_big, count, c->small);
+    run_br(c, c->small, count, c->acc);
+    run_extract_trace(c, c->acc, count, c->glev);
+    run_ss(c, c->glev, count, ggsw_f);
+}
+static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 4096 ? 4096 : g); }
+
+// ---- a1: round schedules ----
+static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint8_t *iv, size_t blk0, int rounds_done,
+                             uint64_t *d_out, bool reference_order)
+{
+    const size_t bits = nb * 128, blkw = (size_t)128 * BIG;
+    const size_t mult_sz = (size_t)16 * 2 * GL;
+    if (!iv) {
+        if (!c->luts) return fail("tx_transcipher: round LUTs not loaded");
+        const size_t set_sz = 4 * mult_sz;
+        // SRV_AES:89-91: clear inv_shift_rows on the public ciphertext bytes
+        std::vector<uint8_t> t(nb * 16);
+        for (size_t b = 0; b < nb; b++)
+            for (int r = 0; r < 4; r++)
+                for (int col = 0; col < 4; col++) t[b * 16 + 4 * col + r] = ct[b * 16 + 4 * ((4 + col - r) % 4) + r];
+        HIP_OK(hipMemcpyAsync(c->d_bytes, t.data(), nb * 16, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));   // t goes out of scope
+        ev_begin(c, F_LIN);
+        for (int m = 0; m < 4; m++)                // SRV_AES:99-118
+            hipLaunchKernelGGL(k_known_rotate, dim3(grid_for(bits)), dim3(256), 0, c->stream, c->d_bytes,
+                               c->luts + (size_t)m * mult_sz, (size_t)2 * GL, c->sm + (size_t)m * nb * blkw, (int)bits);
+        hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 1);
+        ev_end(c);
+        for (int s = 1; s <= 8 && s <= rounds_done; s++) {      // SRV_AES:130-163
+            run_cbs(c, c->st, bits, c->ggsw_f);
+            run_lut(c, c->ggsw_f, nb * 16, c->luts + (size_t)s * set_sz, mult_sz, 4, c->sm);
+            ev_begin(c, F_LIN);
+            hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 1);
+            ev_end(c);
+        }
+        const uint64_t *fin = c->st;
+        if (rounds_done >= 9) {                                  // SRV_AES:166-180
+            run_cbs(c, c->st, bits, c->ggsw_f);
+            run_lut(c, c->ggsw_f, nb * 16, c->luts + (size_t)9 * set_sz, 0, 1, c->sm);
+            fin = c->sm;
+        }
+        if (reference_order) {
+            HIP_OK(hipMemcpyAsync(d_out, fin, bits * BIG * 8, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            ev_begin(c, F_LIN);
+            hipLaunchKernelGGL(k_finalize, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, fin, d_out, (int)nb, 0,
+                               (const uint8_t *)nullptr);
+            ev_end(c);
+        }
+    } else {
+        if (!c->ctr_luts) return fail("tx_transcipher: CTR LUTs not loaded");
+        const size_t set_sz = 3 * mult_sz;
+        std::vector<uint8_t> ctr(nb * 16);
+        for (size_t b = 0; b < nb; b++) {           // iv + (blk0 + b), 128-bit big-endian
+            uint8_t *p = &ctr[b * 16]; memcpy(p, iv, 16);
+            uint64_t add = blk0 + b;
+            for (int i = 15; i >= 0 && add; i--) { uint64_t v = (uint64_t)p[i] + (add & 0xFF); p[i] = (uint8_t)v; add = (add >> 8) + (v >> 8); }
+        }
+        HIP_OK(hipMemcpyAsync(c->d_bytes, ctr.data(), nb * 16, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->d_ct, ct, nb * 16, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        ev_begin(c, F_LIN);
+        for (int m = 0; m < 3; m++)
+            hipLaunchKernelGGL(k_known_rotate, dim3(grid_for(bits)), dim3(256), 0, c->stream, c->d_bytes,
+                               c->ctr_luts + (size_t)m * mult_sz, (size_t)2 * GL, c->sm + (size_t)m * nb * blkw, (int)bits);
+        ev_end(c);
+        for (int s = 1; s <= 9; s++) {
+            ev_begin(c, F_LIN);
+            hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 0);
+            ev_end(c);
+            run_cbs(c, c->st, bits, c->ggsw_f);
+            run_lut(c, c->ggsw_f, nb * 16, c->ctr_luts + (size_t)s * set_sz, mult_sz, s == 9 ? 1 : 3, c->sm);
+        }
+        ev_begin(c, F_LIN);
+        hipLaunchKernelGGL(k_finalize, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, d_out, (int)nb, 1, c->d_ct);
+        ev_end(c);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static const size_t CHUNK_BLOCKS = 128;
+
+static int transcipher_impl(tx_ctx *c, const uint8_t *ct, size_t n_blocks, const uint8_t *iv, int rounds_done,
+                            uint64_t *out, int out_is_device, bool reference_order)
+{
+    if (!c || !ct || !out) return fail("tx_transcipher: null argument");
+    if (!c->have_keys) return fail("tx_transcipher: evaluation keys not loaded");
+    if (n_blocks == 0) return 0;
+    HIP_OK(hipSetDevice(c->device));
+    timing_reset(c);
+    const size_t chunk = n_blocks < CHUNK_BLOCKS ? n_blocks : CHUNK_BLOCKS;
+    if (ensure_ws(c, chunk)) return -1;
+    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        size_t nb = (n_blocks - b0 < chunk) ? n_blocks - b0 : chunk;
+        uint64_t *dst = out_is_device ? out + b0 * 128 * BIG : c->res;
+        if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, dst, reference_order)) return -1;
+        if (!out_is_device)
+            HIP_OK(hipMemcpyAsync(out + b0 * 128 * BIG, c->res, nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    timing_collect(c);
+    return 0;
+}
+
+extern "C" int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv, uint64_t *out_lwe,
+                              int out_is_device)
+{ return transcipher_impl(c, ct_blocks, n_blocks, iv, 9, out_lwe, out_is_device, false); }
+
+extern "C" int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, int rounds_done, uint64_t *out_state)
+{
+    if (rounds_done < 0 || rounds_done > 9) return fail("tx_transcipher_partial: rounds_done out of range");
+    return transcipher_impl(c, ct_blocks, n_blocks, nullptr, rounds_done, out_state, 0, true);
+}
+
+// ---- stage entry points (host buffers) ----
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+};
+#define STAGE_PROLOGUE(name)                                                    \
+    if (!c || !c->have_keys) return fail(name ": context without keys");        \
+    HIP_OK(hipSetDevice(c->device));                                            \
+    timing_reset(c)
+
+extern "C" int tx_stage_lwe_keyswitch(tx_ctx *c, const uint64_t *lwe_big, size_t count, uint64_t *lwe_small)
+{
+    STAGE_PROLOGUE("tx_stage_lwe_keyswitch");
+    DevBuf in, out; const size_t sw = c->p.n + 1;
+    if (in.alloc(count * BIG * 8) || out.alloc(count * sw * 8)) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(in.p, lwe_big, count * BIG * 8, hipMemcpyHostToDevice, c->stream));
+    run_ks(c, (uint64_t *)in.p, count, (uint64_t *)out.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(lwe_small, out.p, count * sw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+extern "C" int tx_stage_blind_rotate(tx_ctx *c, const uint64_t *lwe_small, size_t count, uint64_t *acc)
+{
+    STAGE_PROLOGUE("tx_stage_blind_rotate");
+    DevBuf in, out; const size_t sw = c->p.n + 1;
+    if (in.alloc(count * sw * 8) || out.alloc(count * GL * 8)) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(in.p, lwe_small, count * sw * 8, hipMemcpyHostToDevice, c->stream));
+    run_br(c, (uint64_t *)in.p, count, (uint64_t *)out.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(acc, out.p, count * GL * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+extern "C" int tx_stage_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
+{
+    STAGE_PROLOGUE("tx_stage_extract_trace");
+    DevBuf in, out;
+    if (in.alloc(count * GL * 8) || out.alloc(count * CBS_L * GL * 8)) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(in.p, acc, count * GL * 8, hipMemcpyHostToDevice, c->stream));
+    run_extract_trace(c, (uint64_t *)in.p, count, (uint64_t *)out.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(glev, out.p, count * CBS_L * GL * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+extern "C" int tx_stage_scheme_switch_fourier(tx_ctx *c, const uint64_t *glev, size_t count, double *ggsw_f)
+{
+    STAGE_PROLOGUE("tx_stage_scheme_switch_fourier");
+    DevBuf in, out; const size_t ow = count * CBS_L * KP * KP * H * sizeof(cplx);
+    if (in.alloc(count * CBS_L * GL * 8) || out.alloc(ow)) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(in.p, glev, count * CBS_L * GL * 8, hipMemcpyHostToDevice, c->stream));
+    run_ss(c, (uint64_t *)in.p, count, (cplx *)out.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(ggsw_f, out.p, ow, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+extern "C" int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes, int ctr, int set, int nlut, uint64_t *out)
+{
+    STAGE_PROLOGUE("tx_stage_lut_eval");
+    const uint64_t *base = ctr ? c->ctr_luts : c->luts;
+    if (!base) return fail("tx_stage_lut_eval: LUTs not loaded");
+    const size_t mult_sz = (size_t)16 * 2 * GL, set_sz = (ctr ? 3 : 4) * mult_sz;
+    if (set < 0 || set > 9 || nlut < 1 || nlut > (ctr ? 3 : 4)) return fail("tx_stage_lut_eval: bad set/nlut");
+    DevBuf in, o; const size_t iw = nbytes * 8 * CBS_L * KP * KP * H * sizeof(cplx), ow = (size_t)nlut * nbytes * 8 * BIG * 8;
+    if (in.alloc(iw) || o.alloc(ow)) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(in.p, ggsw_f, iw, hipMemcpyHostToDevice, c->stream));
+    run_lut(c, (cplx *)in.p, nbytes, base + (size_t)set * set_sz, mult_sz, nlut, (uint64_t *)o.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(out, o.p, ow, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+
+// ---- a12: max of n_values u16 (SRV_CMP:34-98, 203-351), log-depth tournament ----
+extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+{
+    if (!c || !lwe_bits || !out_lwe || n_values == 0) return fail("tx_max_u16: bad argument");
+    if (!c->have_keys) return fail("tx_max_u16: evaluation keys not loaded");
+    HIP_OK(hipSetDevice(c->device));
+    timing_reset(c);
+    const size_t v16 = (size_t)16 * BIG;
+    size_t cnt = n_values;
+    // CBS workspace sized in "blocks" of 128 bits
+    if (ensure_ws(c, (cnt * 16 + 127) / 128)) return -1;
+    DevBuf cur, nxt, A, B, E, M0, M1, sela, selb;
+    if (cur.alloc(cnt * v16 * 8) || nxt.alloc(cnt * v16 * 8)) return fail("hipMalloc failed");
+    const size_t maxu = (cnt / 2) * 16;                 // cmux units per step
+    if (A.alloc(maxu * GL * 8) || B.alloc(maxu * GL * 8) || E.alloc(maxu * GL * 8) || M0.alloc(maxu * GL * 8) ||
+        M1.alloc(maxu * GL * 8) || sela.alloc(maxu * 16 * sizeof(int)) || selb.alloc(maxu * 16 * sizeof(int)))
+        return fail("hipMalloc failed");
+    HIP_OK(hipMemcpyAsync(cur.p, lwe_bits, cnt * v16 * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t *pc = (uint64_t *)cur.p, *pn = (uint64_t *)nxt.p;
+    while (cnt > 1) {
+        const size_t pairs = cnt / 2, units = pairs * 16, nx = pairs + (cnt & 1);
+        run_cbs(c, pc, 2 * pairs * 16, c->ggsw_f);
+        // operands as GLWEs: A[q][t] = value 2q bit t, B = value 2q+1 bit t (strided gather by pairs)
+        for (size_t q = 0; q < pairs; q++) {
+            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(16 * GL)), dim3(256), 0, c->stream, pc + (2 * q) * v16,
+                               (uint64_t *)A.p + q * 16 * GL, 16);
+            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(16 * GL)), dim3(256), 0, c->stream, pc + (2 * q + 1) * v16,
+                               (uint64_t *)B.p + q * 16 * GL, 16);
+        }
+        HIP_OK(hipMemcpyAsync(E.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));   // e = a (SURVEY 3.2 fix)
+        // selector tables: for scan step i (bit index i, MSB-first storage), unit (q,t)
+        std::vector<int> ha(units * 16), hb(units * 16);
+        for (int i = 0; i < 16; i++)
+            for (size_t q = 0; q < pairs; q++)
+                for (int t = 0; t < 16; t++) {
+                    ha[(size_t)i * units + q * 16 + t] = (int)((2 * q) * 16 + i);
+                    hb[(size_t)i * units + q * 16 + t] = (int)((2 * q + 1) * 16 + i);
+                }
+        HIP_OK(hipMemcpyAsync(sela.p, ha.data(), ha.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(selb.p, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (int i = 15; i >= 0; i--) {                 // .rev(): least significant bit first
+            const int *sa = (const int *)sela.p + (size_t)i * units, *sb = (const int *)selb.p + (size_t)i * units;
+            ev_begin(c, F_LUT);
+            HIP_OK(hipMemcpyAsync(M0.p, E.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M0.p,
+                               (const uint64_t *)B.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? B : e
+            HIP_OK(hipMemcpyAsync(M1.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M1.p,
+                               (const uint64_t *)E.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? e : A
+            HIP_OK(hipMemcpyAsync(E.p, M0.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)E.p,
+                               (const uint64_t *)M1.p, c->ggsw_f, sa, (int)units, c->tw);    // a_i ? m1 : m0
+            ev_end(c);
+        }
+        hipLaunchKernelGGL(k_extract0, dim3(ew_grid(units * BIG)), dim3(256), 0, c->stream, (const uint64_t *)E.p, pn,
+                           (int)units);
+        if (cnt & 1) HIP_OK(hipMemcpyAsync(pn + pairs * v16, pc + (cnt - 1) * v16, v16 * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(c->stream));
+        std::swap(pc, pn);
+        cnt = nx;
+    }
+    HIP_OK(hipMemcpyAsync(out_lwe, pc, v16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}

@@ -1,0 +1,206 @@
+// tx_device.hpp -- wave-level building blocks for the gfx950 kernels.
+//
+// Execution model: ONE 64-lane wavefront owns one polynomial-sized unit of work (one GLWE
+// ciphertext, one key-switch, ...).  A polynomial of N = 1024 torus coefficients lives in the
+// wave's registers as 16 values per lane: lane t holds coefficients t + 64 m, m = 0..15.  For the
+// f64 negacyclic transform (tfhe-rs fft64 semantics, see oracle/txo_fft.c) coefficients j and
+// j + 512 form one complex point, so lane t holds the 8 complex points t + 64 m -- exactly the
+// operand set of the first radix-8 butterfly.  512 = 8 x 8 x 8: three in-register radix-8 passes
+// separated by two 8x8 transposes through a padded per-wave LDS tile.  The transform output stays
+// in "F-layout" (lane 8 k1 + c, register d  <->  frequency k1 + 8 c + 64 d); keys are stored in
+// that layout as [d][lane] complex so every key load is one coalesced 1 KiB wave access.
+//
+// Floating point: every fused multiply-add is explicit (__builtin_fma) and the translation unit
+// is compiled with -ffp-contract=off, so results are bit-identical to the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace txd {
+
+typedef double2 cplx;
+
+constexpr int N = 1024;           // polynomial size            (aes_instances.rs:79)
+constexpr int H = 512;            // complex points
+constexpr int KP = 3;             // k + 1 polynomials per GLWE (aes_instances.rs:80)
+constexpr int GL = KP * N;        // words per GLWE
+constexpr int BIG = 2 * N + 1;    // words per big LWE
+constexpr int TW_ROWS = 22;       // 8 twist + 7 pass-A + 7 pass-B rows of 64 complex
+constexpr int XPITCH = 65;        // padded pitch (complex) of the per-wave transpose tile
+constexpr int SCRATCH_CPLX = 8 * XPITCH;   // 8320 bytes per wave
+
+__device__ __forceinline__ cplx cmul(cplx x, cplx w)
+{
+    double t = x.y * w.y;
+    double u = x.y * w.x;
+    return make_double2(__builtin_fma(x.x, w.x, -t), __builtin_fma(x.x, w.y, u));
+}
+__device__ __forceinline__ cplx cmulc(cplx x, cplx w)   // x * conj(w)
+{
+    double t = x.y * w.y;
+    double u = x.x * w.y;
+    return make_double2(__builtin_fma(x.x, w.x, t), __builtin_fma(x.y, w.x, -u));
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+#define TXD_SQRT_HALF 0.70710678118654752440
+
+// 8-point DFT in registers, kernel exp(S 2 pi i n k / 8).  Same operand pairing as oracle dft8().
+template <int S>
+__device__ __forceinline__ void dft8(cplx (&v)[8])
+{
+    cplx a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
+    cplx a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
+    cplx a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
+    cplx a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
+    cplx t1, t2, t3;
+    if (S > 0) {
+        t1 = make_double2((b1.x - b1.y) * TXD_SQRT_HALF, (b1.x + b1.y) * TXD_SQRT_HALF);
+        t2 = make_double2(-b2.y, b2.x);
+        t3 = make_double2(-((b3.x + b3.y) * TXD_SQRT_HALF), (b3.x - b3.y) * TXD_SQRT_HALF);
+    } else {
+        t1 = make_double2((b1.x + b1.y) * TXD_SQRT_HALF, (b1.y - b1.x) * TXD_SQRT_HALF);
+        t2 = make_double2(b2.y, -b2.x);
+        t3 = make_double2((b3.y - b3.x) * TXD_SQRT_HALF, -((b3.x + b3.y) * TXD_SQRT_HALF));
+    }
+    cplx p0, q0, p1, q1, d;
+    p0 = cadd(a0, a2); q0 = csub(a0, a2); p1 = cadd(a1, a3); d = csub(a1, a3);
+    q1 = (S > 0) ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+    v[0] = cadd(p0, p1); v[4] = csub(p0, p1); v[2] = cadd(q0, q1); v[6] = csub(q0, q1);
+    p0 = cadd(b0, t2); q0 = csub(b0, t2); p1 = cadd(t1, t3); d = csub(t1, t3);
+    q1 = (S > 0) ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+    v[1] = cadd(p0, p1); v[5] = csub(p0, p1); v[3] = cadd(q0, q1); v[7] = csub(q0, q1);
+}
+
+// Order LDS traffic of one wave: the hardware executes a wave's DS instructions in order, so a
+// compiler-level fence is all that is needed between a tile write and the dependent tile read.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 8x8 transposes through the per-wave tile (pitch 65 complex => conflict-free b128 stores/loads).
+//   xchg_hi: element (lane = 8a+b, reg r)  ->  (lane = 8r+b, reg a)
+//   xchg_lo: element (lane = 8g+b, reg r)  ->  (lane = 8g+r, reg b)
+__device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
+{
+    const int a = lane >> 3, b = lane & 7;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) tile[a * XPITCH + 8 * r + b] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = tile[r * XPITCH + lane];
+}
+__device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
+{
+    const int g8 = lane & ~7, b = lane & 7;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) tile[b * XPITCH + g8 + r] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = tile[r * XPITCH + lane];
+}
+
+// forward transform of the 8 complex points held by this lane; tw = [22][64] table in LDS.
+__device__ __forceinline__ void fft_fwd(cplx (&v)[8], const cplx *tw, cplx *tile, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = cmul(v[m], tw[m * 64 + lane]);
+    dft8<+1>(v);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[(7 + r) * 64 + lane]);
+    xchg_hi(v, tile, lane);
+    dft8<+1>(v);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[(14 + r) * 64 + lane]);
+    xchg_lo(v, tile, lane);
+    dft8<+1>(v);
+}
+// unnormalised inverse; on return v[m] = (a[t + 64 m], a[t + 64 m + 512]) as doubles
+__device__ __forceinline__ void fft_inv(cplx (&v)[8], const cplx *tw, cplx *tile, int lane)
+{
+    dft8<-1>(v);
+    xchg_lo(v, tile, lane);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], tw[(14 + r) * 64 + lane]);
+    dft8<-1>(v);
+    xchg_hi(v, tile, lane);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], tw[(7 + r) * 64 + lane]);
+    dft8<-1>(v);
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = cmulc(v[m], tw[m * 64 + lane]);
+}
+
+// round-half-even(x) mod 2^64 in 7 f64 operations + 1 integer add3 (oracle f64_to_torus)
+__device__ __forceinline__ uint64_t f64_to_torus(double x)
+{
+    double m = x * 0x1p-64;
+    double y = m - __builtin_rint(m);
+    double t1 = __builtin_fma(y, 0x1p64, 0x1.8p84);
+    double h = t1 - 0x1.8p84;
+    double lo = __builtin_fma(y, 0x1p64, -h);
+    double t2 = lo + 0x1.8p52;
+    uint64_t b1 = (uint64_t)__double_as_longlong(t1), b2 = (uint64_t)__double_as_longlong(t2);
+    uint32_t rlo = (uint32_t)b2;
+    uint32_t rhi = (uint32_t)b1 + (uint32_t)(b2 >> 32) - 0x43380000u;
+    return ((uint64_t)rhi << 32) | rlo;
+}
+// torus word as signed 64-bit -> f64 with a single rounding
+__device__ __forceinline__ double torus_to_f64(uint64_t x)
+{
+    return __builtin_fma((double)(int32_t)(x >> 32), 0x1p32, (double)(uint32_t)x);
+}
+
+// ---- signed gadget decomposition (tfhe SignedDecomposer), streamed finest level first ----
+template <int B, int L>
+struct Decomp {
+    static constexpr int BL = B * L;
+    static constexpr int NONREP = 64 - BL;
+    typedef typename std::conditional<(BL <= 31), uint32_t, uint64_t>::type state_t;
+    // closest representable, shifted down: state in [0, 2^BL)
+    __device__ static __forceinline__ state_t init(uint64_t x)
+    {
+        uint64_t s = ((x >> (NONREP - 1)) + 1) >> 1;
+        return (state_t)(s & ((((uint64_t)1) << BL) - 1));
+    }
+    // next digit (level L first, then L-1, ...)
+    __device__ static __forceinline__ int32_t next(state_t &st)
+    {
+        const state_t mask = (((state_t)1) << B) - 1;
+        state_t res = st & mask;
+        st >>= B;
+        state_t carry = ((res - 1) | st) & res;
+        carry >>= (B - 1);
+        st += carry;
+        return (int32_t)res - (int32_t)(carry << B);
+    }
+};
+
+// ---- coefficient-domain helpers on the 16-words-per-lane register layout ----
+// Write a polynomial held in registers to the wave's scratch in natural order.
+__device__ __forceinline__ void poly_to_lds(const uint64_t (&p)[16], uint64_t *s, int lane)
+{
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) s[lane + 64 * m] = p[m];
+    wave_lds_fence();
+}
+// coefficient j of  s(X) * X^rot  (rot in [0, 2N)), s in LDS natural order
+__device__ __forceinline__ uint64_t rot_read(const uint64_t *s, int j, int rot)
+{
+    int src = j - rot;                 // in (-2N, N)
+    uint64_t neg = 0;
+    if (src < 0) { src += N; neg = ~neg; }
+    if (src < 0) { src += N; neg = ~neg; }
+    uint64_t x = s[src];
+    return (x ^ neg) - neg;
+}
+
+}  // namespace txd

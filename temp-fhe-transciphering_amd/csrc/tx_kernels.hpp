@@ -1,0 +1,732 @@
+// tx_kernels.hpp -- gfx950 kernels of the transciphering hot path.
+//
+// Work decomposition: one wavefront per unit (ciphertext / key-switch / LUT accumulator), four
+// units per 256-thread workgroup, which share the twiddle table in LDS.  Units are independent,
+// so a launch of U units is ceil(U/4) workgroups; with U in the thousands (128 bits x blocks) the
+// grid is many times the 256 CUs.  All workgroups walk the evaluation key in the same order, so
+// the key stream (72 KiB per blind-rotation step) is served from L2 / Infinity Cache, not HBM.
+#pragma once
+#include "tx_device.hpp"
+#include <type_traits>
+
+namespace txd {
+
+// AES_TIGHT decomposition constants (cbs_lib/src/aes_instances.rs:82-95), compile-time here
+constexpr int PBS_B = 23, PBS_L = 1;
+constexpr int KS_B = 4, KS_L = 3, KS_N = 256;
+constexpr int AUTO_B = 13, AUTO_L = 3, AUTO_SPLIT = 41;
+constexpr int SS_B = 17, SS_L = 2;
+constexpr int CBS_B = 2, CBS_L = 7;
+constexpr int LOG_LUT = 3;
+constexpr int LOGN = 10;
+
+constexpr int WAVES = 4;                                   // units per workgroup
+constexpr size_t LDS_BYTES = (size_t)(TW_ROWS * 64 + WAVES * SCRATCH_CPLX) * sizeof(cplx);
+
+struct WaveCtx {
+    const cplx *tw;     // LDS twiddles
+    cplx *tile;         // this wave's LDS tile
+    uint64_t *pl;       // same memory viewed as 1024 torus words
+    int lane;
+    int unit;           // global unit index of this wave
+};
+
+// loads the twiddle table into LDS; returns the per-wave context.  Contains the only
+// workgroup-wide barrier of every kernel.
+__device__ __forceinline__ WaveCtx wave_setup(const cplx *tw_g, unsigned char *lds)
+{
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < TW_ROWS * 64; i += blockDim.x) tw[i] = tw_g[i];
+    __syncthreads();
+    WaveCtx w;
+    int wave = threadIdx.x >> 6;
+    w.tw = tw;
+    w.tile = tw + TW_ROWS * 64 + wave * SCRATCH_CPLX;
+    w.pl = reinterpret_cast<uint64_t *>(w.tile);
+    w.lane = threadIdx.x & 63;
+    w.unit = blockIdx.x * WAVES + wave;
+    return w;
+}
+
+__device__ __forceinline__ uint32_t modswitch(uint64_t x)
+{   // fast_pbs_modulus_switch(x, N, 0, LOG_LUT)   (pbs.rs:84-89)
+    uint64_t o = x >> (64 - LOGN - 2 + LOG_LUT);
+    o += (o & 1);
+    o >>= 1;
+    return (uint32_t)(o << LOG_LUT);
+}
+
+__device__ __forceinline__ void fmac8(cplx (&acc)[8], const cplx (&d)[8], const cplx *key, int lane)
+{   // pointwise acc += d * key on this lane's 8 frequencies; key is [8][64] complex (F-layout)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        cplx g = key[r * 64 + lane];
+        double re = acc[r].x, im = acc[r].y;
+        re = __builtin_fma(d[r].x, g.x, re);
+        re = __builtin_fma(-d[r].y, g.y, re);
+        im = __builtin_fma(d[r].x, g.y, im);
+        im = __builtin_fma(d[r].y, g.x, im);
+        acc[r] = make_double2(re, im);
+    }
+}
+
+// One row of an external product: decompose the 16 coefficients of this lane (lo[m] = coeff
+// t+64m, hi[m] = coeff t+64m+512), level L (finest) first, transform each digit polynomial and
+// accumulate it against the key row.  key points at GGSW element [lev 0][row r][col 0];
+// lev_stride / col_stride in complex units.  NCOL output columns.
+template <int B, int L, int NCOL>
+__device__ __forceinline__ void extprod_row(cplx (&F)[NCOL][8], const uint64_t (&lo)[8], const uint64_t (&hi)[8],
+                                            const cplx *key, size_t lev_stride, size_t col_stride, const WaveCtx &w)
+{
+    typedef Decomp<B, L> D;
+    typename D::state_t slo[8], shi[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { slo[m] = D::init(lo[m]); shi[m] = D::init(hi[m]); }
+#pragma unroll 1
+    for (int i = 0; i < L; i++) {
+        const int lev = L - 1 - i;
+        cplx v[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
+        fft_fwd(v, w.tw, w.tile, w.lane);
+#pragma unroll
+        for (int c = 0; c < NCOL; c++) fmac8(F[c], v, key + lev * lev_stride + c * col_stride, w.lane);
+    }
+}
+
+// inverse-transform a Fourier accumulator and add the rounded result into 16 torus words
+__device__ __forceinline__ void inv_add(cplx (&F)[8], uint64_t (&p)[16], const WaveCtx &w)
+{
+    fft_inv(F, w.tw, w.tile, w.lane);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { p[m] += f64_to_torus(F[m].x); p[m + 8] += f64_to_torus(F[m].y); }
+}
+
+template <int NCOL>
+__device__ __forceinline__ void zero_f(cplx (&F)[NCOL][8])
+{
+#pragma unroll
+    for (int c = 0; c < NCOL; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) F[c][r] = make_double2(0.0, 0.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// key-side transform: torus polynomial -> Fourier (F-layout), scaled by 2/N.
+// mode 0: as is; mode 1: low `split` bits; mode 2: x >> split   (fourier_glwe_keyswitch.rs:188-199)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_torus(const uint64_t *in, cplx *out, int npoly, int mode, int split,
+                                                   const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= npoly) return;
+    const uint64_t *p = in + (size_t)w.unit * N;
+    cplx v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        uint64_t a = p[w.lane + 64 * m], b = p[w.lane + 64 * m + 512];
+        if (mode == 1) { a = (a << (64 - split)) >> (64 - split); b = (b << (64 - split)) >> (64 - split); }
+        if (mode == 2) { a >>= split; b >>= split; }
+        v[m] = make_double2(torus_to_f64(a), torus_to_f64(b));
+    }
+    fft_fwd(v, w.tw, w.tile, w.lane);
+    cplx *o = out + (size_t)w.unit * H;
+#pragma unroll
+    for (int r = 0; r < 8; r++) o[r * 64 + w.lane] = make_double2(v[r].x * 0x1p-9, v[r].y * 0x1p-9);
+}
+
+// ------------------------------------------------------------------------------------------
+// N = 256 transform (LWE key switch): 128 complex points, 2 per lane, radix-2 across lanes.
+// tws: [128 twist][64 w] complex in LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx shfl_xor_c(cplx v, int mask)
+{
+    return make_double2(__shfl_xor(v.x, mask), __shfl_xor(v.y, mask));
+}
+__device__ __forceinline__ void fft128_fwd(cplx &x0, cplx &x1, const cplx *twist, const cplx *wt, int lane)
+{
+    x0 = cmul(x0, twist[lane]);
+    x1 = cmul(x1, twist[lane + 64]);
+    {
+        cplx u = x0, v = x1;
+        x0 = cadd(u, v);
+        x1 = cmul(csub(u, v), wt[lane]);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const bool upper = (lane & s) != 0;
+        const cplx wv = wt[(lane & (s - 1)) * (64 / s)];
+        cplx o0 = shfl_xor_c(x0, s), o1 = shfl_xor_c(x1, s);
+        x0 = upper ? cmul(csub(o0, x0), wv) : cadd(x0, o0);
+        x1 = upper ? cmul(csub(o1, x1), wv) : cadd(x1, o1);
+    }
+}
+__device__ __forceinline__ void fft128_inv(cplx &x0, cplx &x1, const cplx *twist, const cplx *wt, int lane)
+{
+#pragma unroll
+    for (int s = 1; s <= 32; s <<= 1) {
+        const bool upper = (lane & s) != 0;
+        const cplx wv = wt[(lane & (s - 1)) * (64 / s)];
+        cplx s0 = upper ? cmulc(x0, wv) : x0, s1 = upper ? cmulc(x1, wv) : x1;
+        cplx r0 = shfl_xor_c(s0, s), r1 = shfl_xor_c(s1, s);
+        x0 = upper ? csub(r0, s0) : cadd(s0, r0);
+        x1 = upper ? csub(r1, s1) : cadd(s1, r1);
+    }
+    {
+        cplx u = x0, v = cmulc(x1, wt[lane]);
+        x0 = cadd(u, v);
+        x1 = csub(u, v);
+    }
+    x0 = cmulc(x0, twist[lane]);
+    x1 = cmulc(x1, twist[lane + 64]);
+}
+
+__global__ __launch_bounds__(256) void k_fwd_torus256(const uint64_t *in, cplx *out, int npoly, const cplx *tw256_g)
+{
+    __shared__ cplx tws[192];
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) tws[i] = tw256_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, unit = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (unit >= npoly) return;
+    const uint64_t *p = in + (size_t)unit * KS_N;
+    cplx x0 = make_double2(torus_to_f64(p[lane]), torus_to_f64(p[lane + 128]));
+    cplx x1 = make_double2(torus_to_f64(p[lane + 64]), torus_to_f64(p[lane + 192]));
+    fft128_fwd(x0, x1, tws, tws + 128, lane);
+    cplx *o = out + (size_t)unit * 128;
+    o[lane] = make_double2(x0.x * 0x1p-7, x0.y * 0x1p-7);
+    o[lane + 64] = make_double2(x1.x * 0x1p-7, x1.y * 0x1p-7);
+}
+
+// ------------------------------------------------------------------------------------------
+// a4: LWE key switch 2048 -> n as a GLWE key switch at N_c = 256
+// (fourier_glwe_keyswitch.rs:213-379, glwe_conv.rs:27-43).  One wave per LWE.
+// ksk_f: [kin = 8][lev 3][Kout][128] complex.
+// ------------------------------------------------------------------------------------------
+constexpr int KS_MAXKOUT = 5;
+__global__ __launch_bounds__(256) void k_lwe_keyswitch(const uint64_t *in, uint64_t *out, int count, int n,
+                                                       const cplx *ksk_f, const cplx *tw256_g)
+{
+    __shared__ cplx tws[192];
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) tws[i] = tw256_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, unit = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (unit >= count) return;
+    const cplx *twist = tws, *wt = tws + 128;
+    const int kout = n / KS_N, Kout = kout + 1, kin = 2 * N / KS_N;
+    const uint64_t *ct = in + (size_t)unit * BIG;
+    cplx F[KS_MAXKOUT][2];
+#pragma unroll
+    for (int c = 0; c < KS_MAXKOUT; c++) { F[c][0] = make_double2(0, 0); F[c][1] = make_double2(0, 0); }
+    typedef Decomp<KS_B, KS_L> D;
+    for (int q = 0; q < kin; q++) {
+        const uint64_t *a = ct + q * KS_N;
+        // g[0] = a[0], g[j] = -a[256 - j]; this lane holds j = lane + 64 r, r = 0..3
+        uint64_t g[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int j = lane + 64 * r;
+            g[r] = (j == 0) ? a[0] : (uint64_t)0 - a[KS_N - j];
+        }
+        D::state_t st[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) st[r] = D::init(g[r]);
+#pragma unroll 1
+        for (int i = 0; i < KS_L; i++) {
+            const int lev = KS_L - 1 - i;
+            // complex point lane      = (g[lane],      g[lane + 128])  -> regs r = 0, 2
+            // complex point lane + 64 = (g[lane + 64], g[lane + 192])  -> regs r = 1, 3
+            double d0 = (double)D::next(st[0]), d1 = (double)D::next(st[1]);
+            double d2 = (double)D::next(st[2]), d3 = (double)D::next(st[3]);
+            cplx x0 = make_double2(d0, d2), x1 = make_double2(d1, d3);
+            fft128_fwd(x0, x1, twist, wt, lane);
+            const cplx *key = ksk_f + ((size_t)(q * KS_L + lev) * Kout) * 128;
+#pragma unroll
+            for (int c = 0; c < KS_MAXKOUT; c++)
+                if (c < Kout) {
+                    cplx g0 = key[c * 128 + lane], g1 = key[c * 128 + lane + 64];
+                    double re = F[c][0].x, im = F[c][0].y;
+                    re = __builtin_fma(x0.x, g0.x, re); re = __builtin_fma(-x0.y, g0.y, re);
+                    im = __builtin_fma(x0.x, g0.y, im); im = __builtin_fma(x0.y, g0.x, im);
+                    F[c][0] = make_double2(re, im);
+                    re = F[c][1].x; im = F[c][1].y;
+                    re = __builtin_fma(x1.x, g1.x, re); re = __builtin_fma(-x1.y, g1.y, re);
+                    im = __builtin_fma(x1.x, g1.y, im); im = __builtin_fma(x1.y, g1.x, im);
+                    F[c][1] = make_double2(re, im);
+                }
+        }
+    }
+    uint64_t *o = out + (size_t)unit * (n + 1);
+#pragma unroll
+    for (int c = 0; c < KS_MAXKOUT; c++)
+        if (c < Kout) {
+            cplx x0 = F[c][0], x1 = F[c][1];
+            fft128_inv(x0, x1, twist, wt, lane);
+            uint64_t r[4] = { f64_to_torus(x0.x), f64_to_torus(x1.x), f64_to_torus(x0.y), f64_to_torus(x1.y) };
+            if (c < kout) {
+                // sample extract at 0: out[m] = res[0] (m = 0), -res[256 - m] otherwise
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    int j = lane + 64 * rr;
+                    if (j == 0) o[c * KS_N] = r[rr]; else o[c * KS_N + KS_N - j] = (uint64_t)0 - r[rr];
+                }
+            } else if (lane == 0) {
+                o[n] = r[0] + ct[2 * N];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// a5: multi-value blind rotation of the CBS test vector
+// (ggsw_conv.rs:250-300, pbs.rs:70-146).  One wave per input LWE; the accumulator (3 x 1024
+// torus words) stays in registers for all n CMux steps; bsk_f: [n][row 3][col 3][512] complex.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t test_vector(int i)
+{   // coefficient i in [0, N) of the accumulator built at ggsw_conv.rs:252-261
+    const int sh = 63 - CBS_B * ((i & ((1 << LOG_LUT) - 1)) + 1);
+    const uint64_t v = (uint64_t)1 << sh;
+    return (i < N / 2) ? (uint64_t)0 - v : v;
+}
+
+__global__ __launch_bounds__(256) void k_blind_rotate(const uint64_t *lwe, uint64_t *acc_out, int count, int n,
+                                                      const cplx *bsk_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= count) return;
+    const uint64_t *ct = lwe + (size_t)w.unit * (n + 1);
+    const int lane = w.lane;
+    uint64_t acc[KP][16];
+    {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+        const int rot = 2 * N - (int)modswitch(ct[n]);      // X^(-b) = X^(2N - b); b in [0, 2N]
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            acc[0][m] = 0; acc[1][m] = 0;
+            int src = lane + 64 * m - rot;                  // in [-2N, N)
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            acc[2][m] = (x ^ neg) - neg;
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const uint64_t a = ct[i];
+        if (a == 0) continue;                               // pbs.rs:111
+        const int rot = (int)modswitch(a);
+        cplx F[KP][8];
+        zero_f(F);
+#pragma unroll
+        for (int q = 0; q < KP; q++) {
+            // ct1 = acc * X^rot - acc     (pbs.rs:125-134)
+            poly_to_lds(acc[q], w.pl, lane);
+            uint64_t lo[8], hi[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                lo[m] = rot_read(w.pl, lane + 64 * m, rot) - acc[q][m];
+                hi[m] = rot_read(w.pl, lane + 64 * m + 512, rot) - acc[q][m + 8];
+            }
+            const cplx *key = bsk_f + ((size_t)i * PBS_L * KP + q) * KP * H;
+            extprod_row<PBS_B, PBS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
+        }
+#pragma unroll
+        for (int c = 0; c < KP; c++) inv_add(F[c], acc[c], w);
+    }
+    uint64_t *o = acc_out + (size_t)w.unit * GL;
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = acc[q][m];
+}
+
+// ------------------------------------------------------------------------------------------
+// a6 + a7: per (ciphertext, level): extract level from the rotated accumulator, divide by N
+// (mod switch), LWE -> GLWE const, then the homomorphic trace: 10 x (automorphism + GLWE key
+// switch with the 41/23-bit split key)   (ggsw_conv.rs:304-316, automorphism.rs:134-233,
+// fourier_glwe_keyswitch.rs:213-342).  auto_f: [split 2][idx 10][q 2][lev 3][col 3][512].
+// ------------------------------------------------------------------------------------------
+// scatter polynomial p (registers) to X -> X^t in LDS, read it back in natural order
+__device__ __forceinline__ void automorph(const uint64_t (&p)[16], uint64_t (&o)[16], uint32_t t, const WaveCtx &w)
+{
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        uint32_t i = w.lane + 64 * m;
+        uint32_t it = i * t;
+        uint64_t neg = (uint64_t)0 - (uint64_t)((it >> LOGN) & 1);
+        w.pl[it & (N - 1)] = (p[m] ^ neg) - neg;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) o[m] = w.pl[w.lane + 64 * m];
+}
+
+// one trace on the GLWE held in g[3][16]
+__device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *auto_f, size_t split_stride, const WaveCtx &w)
+{
+#pragma unroll 1
+    for (int idx = 0; idx < LOGN; idx++) {
+        const uint32_t t = (N >> idx) + 1;
+        cplx F[2][KP][8];
+        zero_f(F[0]); zero_f(F[1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint64_t pw[16];
+            automorph(g[q], pw, t, w);
+            typedef Decomp<AUTO_B, AUTO_L> D;
+            D::state_t slo[8], shi[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) { slo[m] = D::init(pw[m]); shi[m] = D::init(pw[m + 8]); }
+#pragma unroll 1
+            for (int i = 0; i < AUTO_L; i++) {
+                const int lev = AUTO_L - 1 - i;
+                cplx v[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) v[m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
+                fft_fwd(v, w.tw, w.tile, w.lane);
+                const cplx *key = auto_f + ((((size_t)idx * 2 + q) * AUTO_L) + lev) * KP * H;
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int c = 0; c < KP; c++) fmac8(F[s][c], v, key + s * split_stride + c * H, w.lane);
+            }
+        }
+        // g += KS(g(X^t)) = (0, 0, body(X^t)) + lo + 2^41 hi
+        uint64_t pb[16];
+        automorph(g[2], pb, t, w);
+#pragma unroll
+        for (int c = 0; c < KP; c++) {
+            uint64_t lo[16], hi[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) { lo[m] = 0; hi[m] = 0; }
+            inv_add(F[0][c], lo, w);
+            inv_add(F[1][c], hi, w);
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                uint64_t ks = lo[m] + (hi[m] << AUTO_SPLIT);
+                if (c == KP - 1) ks += pb[m];
+                g[c][m] += ks;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_extract_trace(const uint64_t *acc, uint64_t *glev, int count,
+                                                       const cplx *auto_f, size_t split_stride, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= count * CBS_L) return;
+    const int ctx = w.unit / CBS_L, lvl = w.unit % CBS_L;         // lvl = level - 1 = rotation k
+    const uint64_t *a = acc + (size_t)ctx * GL;
+    const int lane = w.lane;
+    uint64_t g[KP][16];
+    // buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const:
+    //   mask: g[j] = buf[0] >> 10 (j = 0), -((-buf[j]) >> 10) otherwise; body: (buf[0] + c) >> 10, 0...
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int j = lane + 64 * m, s = j + lvl;
+            uint64_t x = (s < N) ? a[q * N + s] : (uint64_t)0 - a[q * N + s - N];
+            g[q][m] = (j == 0) ? (x >> LOGN) : (uint64_t)0 - (((uint64_t)0 - x) >> LOGN);
+        }
+#pragma unroll
+    for (int m = 0; m < 16; m++) g[2][m] = 0;
+    if (lane == 0) g[2][0] = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
+    trace_regs(g, auto_f, split_stride, w);
+    uint64_t *o = glev + (size_t)w.unit * GL;
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = g[q][m];
+}
+
+// trace_assign alone on `count` GLWEs in place (unit parity for a7)
+__global__ __launch_bounds__(256) void k_trace(uint64_t *glwe, int count, const cplx *auto_f, size_t split_stride,
+                                               const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= count) return;
+    uint64_t *p = glwe + (size_t)w.unit * GL;
+    uint64_t g[KP][16];
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) g[q][m] = p[q * N + w.lane + 64 * m];
+    trace_regs(g, auto_f, split_stride, w);
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) p[q * N + w.lane + 64 * m] = g[q][m];
+}
+
+// ------------------------------------------------------------------------------------------
+// a8 + a9: scheme switching GLev -> GGSW, emitted directly in the Fourier domain
+// (ggsw_conv.rs:163-193, SRV_AES:430-436).  Unit = (ciphertext, level).
+// ss_f: [i 2][lev 2][row 3][col 3][512];  out: [unit][row 3][col 3][512] complex.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_fourier_scaled(const uint64_t (&p)[16], cplx *o, const WaveCtx &w)
+{
+    cplx v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = make_double2(torus_to_f64(p[m]), torus_to_f64(p[m + 8]));
+    fft_fwd(v, w.tw, w.tile, w.lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) o[r * 64 + w.lane] = make_double2(v[r].x * 0x1p-9, v[r].y * 0x1p-9);
+}
+
+__global__ __launch_bounds__(256) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
+                                                       const cplx *ss_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= units) return;
+    const uint64_t *gp = glev + (size_t)w.unit * GL;
+    cplx *o = ggsw_f + (size_t)w.unit * KP * KP * H;
+    uint64_t in[KP][16];
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) in[q][m] = gp[q * N + w.lane + 64 * m];
+#pragma unroll 1
+    for (int i = 0; i < 2; i++) {
+        cplx F[KP][8];
+        zero_f(F);
+#pragma unroll
+        for (int r = 0; r < KP; r++) {
+            uint64_t lo[8], hi[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) { lo[m] = in[r][m]; hi[m] = in[r][m + 8]; }
+            const cplx *key = ss_f + (((size_t)i * SS_L) * KP + r) * KP * H;
+            extprod_row<SS_B, SS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
+        }
+#pragma unroll
+        for (int c = 0; c < KP; c++) {
+            uint64_t row[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) row[m] = 0;
+            inv_add(F[c], row, w);
+            store_fourier_scaled(row, o + ((size_t)i * KP + c) * H, w);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KP; c++) store_fourier_scaled(in[c], o + ((size_t)2 * KP + c) * H, w);
+}
+
+// ------------------------------------------------------------------------------------------
+// a10: CMux tree over the 8 selector GGSWs of a byte (SRV_AES:550-588).
+// Unit = (byte, lut, acc_idx).  ggsw_f: [byte*8 + bit][lev 7][row 3][col 3][512].
+// luts: accumulators [lut][byte%16][acc 2][3][N] with strides in words.
+// out: [(lut*nbytes + byte)*8 + 4*acc + i] big LWEs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sample_extract_store(const uint64_t (&p0)[16], const uint64_t (&p1)[16],
+                                                     const uint64_t (&p2)[16], int nth, uint64_t *o, const WaveCtx &w)
+{
+    // lwe[q*N + m] = a_q[nth - m] (m <= nth), -a_q[N + nth - m] otherwise; body = b[nth]
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (q == 0) poly_to_lds(p0, w.pl, w.lane); else poly_to_lds(p1, w.pl, w.lane);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int j = w.lane + 64 * m;
+            int src = nth - j;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = w.pl[src];
+            o[q * N + j] = (x ^ neg) - neg;
+        }
+    }
+    poly_to_lds(p2, w.pl, w.lane);
+    if (w.lane == 0) o[2 * N] = w.pl[nth];
+}
+
+__global__ __launch_bounds__(256) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
+                                                  size_t byte_stride, uint64_t *out, int nbytes, int nlut,
+                                                  const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= nbytes * nlut * 2) return;
+    const int byte = w.unit / (nlut * 2), lut = (w.unit >> 1) % nlut, acc_idx = w.unit & 1;
+    const int lane = w.lane;
+    const uint64_t *lp = luts + (size_t)lut * lut_stride + (size_t)(byte & 15) * byte_stride + (size_t)acc_idx * GL;
+    uint64_t acc[KP][16];
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) acc[q][m] = lp[q * N + lane + 64 * m];
+    const size_t ggsw_sz = (size_t)CBS_L * KP * KP * H;
+#pragma unroll 1
+    for (int bit = 0; bit < 8; bit++) {
+        const int rot = 2 * N - (1 << bit);                 // X^(-2^bit)
+        const cplx *gg = ggsw_f + ((size_t)byte * 8 + bit) * ggsw_sz;
+        cplx F[KP][8];
+        zero_f(F);
+#pragma unroll
+        for (int r = 0; r < KP; r++) {
+            uint64_t lo[8], hi[8];
+            poly_to_lds(acc[r], w.pl, lane);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                lo[m] = rot_read(w.pl, lane + 64 * m, rot) - acc[r][m];
+                hi[m] = rot_read(w.pl, lane + 64 * m + 512, rot) - acc[r][m + 8];
+            }
+            extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
+        }
+#pragma unroll
+        for (int c = 0; c < KP; c++) inv_add(F[c], acc[c], w);
+    }
+    const size_t big = BIG;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        uint64_t *o = out + (((size_t)lut * nbytes + byte) * 8 + acc_idx * 4 + i) * big;
+        sample_extract_store(acc[0], acc[1], acc[2], 256 * i, o, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cmux (SRV_CMP:81-95 via tfhe cmux_assign): ct0 += g (x) (ct1 - ct0), batched: unit u uses
+// selector sel[u] (index into ggsw_f), GLWEs ct0[u], ct1[u] (ct1 is not modified).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
+                                              int units, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    WaveCtx w = wave_setup(tw_g, lds);
+    if (w.unit >= units) return;
+    uint64_t *p0 = ct0 + (size_t)w.unit * GL;
+    const uint64_t *p1 = ct1 + (size_t)w.unit * GL;
+    const cplx *gg = ggsw_f + (size_t)sel[w.unit] * CBS_L * KP * KP * H;
+    cplx F[KP][8];
+    zero_f(F);
+#pragma unroll
+    for (int r = 0; r < KP; r++) {
+        uint64_t lo[8], hi[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            lo[m] = p1[r * N + w.lane + 64 * m] - p0[r * N + w.lane + 64 * m];
+            hi[m] = p1[r * N + w.lane + 64 * m + 512] - p0[r * N + w.lane + 64 * m + 512];
+        }
+        extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
+    }
+#pragma unroll
+    for (int c = 0; c < KP; c++) {
+        uint64_t row[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) row[m] = p0[c * N + w.lane + 64 * m];
+        inv_add(F[c], row, w);
+#pragma unroll
+        for (int m = 0; m < 16; m++) p0[c * N + w.lane + 64 * m] = row[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// element-wise / permutation kernels on big LWEs (bandwidth-bound, 16-byte accesses where the
+// 2049-word pitch allows: it does not -- 2049 is odd -- so 8-byte coalesced accesses)
+// ------------------------------------------------------------------------------------------
+// a2: known_rotate_keyed_lut (aes_he.rs:64-93): for block b, bit i: extract coefficient
+// lut_idx*256 + byte value of accumulator acc_idx of byte.  One wave per output LWE.
+__global__ __launch_bounds__(256) void k_known_rotate(const uint8_t *bytes /* nblocks x 16 */, const uint64_t *lut_set,
+                                                      size_t byte_stride, uint64_t *out, int nbits)
+{
+    const int lane = threadIdx.x & 63, unit = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (unit >= nbits) return;
+    const int blk = unit >> 7, i = unit & 127, byte = i >> 3, bit = i & 7;
+    const int acc = bit >> 2, lut = bit & 3;
+    const int nth = lut * 256 + bytes[blk * 16 + byte];
+    const uint64_t *g = lut_set + (size_t)byte * byte_stride + (size_t)acc * GL;
+    uint64_t *o = out + (size_t)unit * BIG;
+    for (int q = 0; q < 2; q++)
+        for (int j = lane; j < N; j += 64) {
+            int src = nth - j;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = g[q * N + src];
+            o[q * N + j] = (x ^ neg) - neg;
+        }
+    if (lane == 0) o[2 * N] = g[2 * N + nth];
+}
+
+// a3: he_inv_mix_columns_precomp + he_inv_shift_rows (SRV_AES:195-265) fused:
+// st[dst(r,c)] = s14[r,c'] + s11[r+1,c'] + s13[r+2,c'] + s9[r+3,c'] with c' = (4 - r + c) % 4
+// forward variant (aes_he.rs:441-474 + 348-368): ShiftRows first, then MixColumns.
+// sm: [mult][block][128][BIG]; inverse != 0: mults = x9,x11,x13,x14; else x1,x2,x3.
+__global__ __launch_bounds__(256) void k_linear(const uint64_t *sm, uint64_t *st, int nblocks, int inverse)
+{
+    const size_t total = (size_t)nblocks * 128 * BIG;
+    const size_t mstride = total;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t lwe = e / BIG, word = e % BIG;
+        int blk = (int)(lwe >> 7), i = (int)(lwe & 127), byte = i >> 3, bit = i & 7;
+        int c = byte >> 2, r = byte & 3;
+        size_t base = (size_t)blk * 128;
+        uint64_t v;
+        if (inverse) {
+            int cs = (4 - r + c) & 3;          // source column after the inverse shift
+            // mixed[r, cs] = s14[r,cs] + s11[r+1,cs] + s13[r+2,cs] + s9[r+3,cs]
+            size_t b14 = (base + (size_t)(4 * cs + r) * 8 + bit) * BIG + word;
+            size_t b11 = (base + (size_t)(4 * cs + ((r + 1) & 3)) * 8 + bit) * BIG + word;
+            size_t b13 = (base + (size_t)(4 * cs + ((r + 2) & 3)) * 8 + bit) * BIG + word;
+            size_t b9 = (base + (size_t)(4 * cs + ((r + 3) & 3)) * 8 + bit) * BIG + word;
+            v = sm[3 * mstride + b14] + sm[1 * mstride + b11] + sm[2 * mstride + b13] + sm[0 * mstride + b9];
+        } else {
+            // shifted[r', c] = s[r', (r' + c) % 4];  out[r,c] = 2 sh[r,c] + 3 sh[r+1,c] + sh[r+2,c] + sh[r+3,c]
+            int r1 = (r + 1) & 3, r2 = (r + 2) & 3, r3 = (r + 3) & 3;
+            size_t a2 = (base + (size_t)(4 * ((r + c) & 3) + r) * 8 + bit) * BIG + word;
+            size_t a3 = (base + (size_t)(4 * ((r1 + c) & 3) + r1) * 8 + bit) * BIG + word;
+            size_t a1 = (base + (size_t)(4 * ((r2 + c) & 3) + r2) * 8 + bit) * BIG + word;
+            size_t a0 = (base + (size_t)(4 * ((r3 + c) & 3) + r3) * 8 + bit) * BIG + word;
+            v = sm[1 * mstride + a2] + sm[2 * mstride + a3] + sm[0 * mstride + a1] + sm[0 * mstride + a0];
+        }
+        st[e] = v;
+    }
+}
+
+// final byte-wise bit reversal (SRV_AES:182-189); ctr != 0 additionally applies ShiftRows of the
+// last forward round and XORs the public ciphertext bits (adds 2^63 to the body).
+__global__ __launch_bounds__(256) void k_finalize(const uint64_t *st, uint64_t *out, int nblocks, int ctr,
+                                                  const uint8_t *ct_bytes)
+{
+    const size_t total = (size_t)nblocks * 128 * BIG;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t lwe = e / BIG, word = e % BIG;
+        int blk = (int)(lwe >> 7), i = (int)(lwe & 127), byte = i >> 3, bit = 7 - (i & 7);
+        int c = byte >> 2, r = byte & 3;
+        int sbyte = ctr ? 4 * ((r + c) & 3) + r : byte;
+        uint64_t v = st[(((size_t)blk * 128) + (size_t)sbyte * 8 + bit) * BIG + word];
+        if (ctr && word == BIG - 1 && ((ct_bytes[blk * 16 + byte] >> bit) & 1)) v += (uint64_t)1 << 63;
+        out[e] = v;
+    }
+}
+
+// LWE (big) -> GLWE with the message in the constant coefficient (glwe_conv.rs:12-44), batched
+__global__ __launch_bounds__(256) void k_lwe_to_glwe(const uint64_t *lwe, uint64_t *glwe, int count)
+{
+    const size_t total = (size_t)count * GL;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t u = e / GL; int w = (int)(e % GL), q = w / N, j = w % N;
+        const uint64_t *a = lwe + u * BIG;
+        uint64_t v;
+        if (q < 2) v = (j == 0) ? a[q * N] : (uint64_t)0 - a[q * N + N - j];
+        else v = (j == 0) ? a[2 * N] : 0;
+        glwe[e] = v;
+    }
+}
+// sample extract at 0 from GLWEs (batched)
+__global__ __launch_bounds__(256) void k_extract0(const uint64_t *glwe, uint64_t *lwe, int count)
+{
+    const size_t total = (size_t)count * BIG;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t u = e / BIG; int w = (int)(e % BIG);
+        const uint64_t *g = glwe + u * GL;
+        uint64_t v;
+        if (w == 2 * N) v = g[2 * N];
+        else { int q = w / N, m = w % N; v = (m == 0) ? g[q * N] : (uint64_t)0 - g[q * N + N - m]; }
+        lwe[e] = v;
+    }
+}
+
+}  // namespace txd

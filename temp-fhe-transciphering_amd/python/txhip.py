@@ -1,0 +1,196 @@
+"""ctypes binding of libtfhe_mi355x.so (the C ABI of include/tfhe_mi355x.h).
+
+Used by tests/, bench.py and __graft_entry__.py; mirrors the call sequence of the reference's
+server stage (`main` of server_encrypted_aes_decryption.rs:599-707): create a context, load the
+evaluation keys and the transciphering key once, then transcipher batches of AES blocks.
+There is no fallback: if the shared library or a HIP device is missing, calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_DIR, "libtfhe_mi355x.so")
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+f64p = C.POINTER(C.c_double)
+
+
+class TxParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "n", "N", "k", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level", "ks_N",
+        "auto_base_log", "auto_level", "auto_split", "ss_base_log", "ss_level",
+        "cbs_base_log", "cbs_level", "log_lut_count")] + [("lwe_std", C.c_double), ("glwe_std", C.c_double)]
+
+
+class TxTiming(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_keyswitch", "ms_blind_rotate", "ms_trace", "ms_scheme_switch",
+                                          "ms_lut_eval", "ms_linear", "ms_total")] + \
+               [(n, C.c_uint32) for n in ("n_keyswitch", "n_blind_rotate", "n_trace", "n_scheme_switch",
+                                          "n_lut_eval", "n_linear")]
+
+
+EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys",
+           "tx_load_round_luts", "tx_load_ctr_luts", "tx_transcipher", "tx_transcipher_partial", "tx_max_u16",
+           "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
+           "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles"]
+
+_LIB = None
+
+
+class TxError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TxError("libtfhe_mi355x.so is not built (run __graft_entry__.build()); no fallback exists")
+        L = C.CDLL(LIB_PATH)
+        L.tx_last_error.restype = C.c_char_p
+        L.tx_create.restype = C.c_void_p
+        L.tx_create.argtypes = [C.POINTER(TxParams), C.c_int]
+        L.tx_destroy.argtypes = [C.c_void_p]
+        L.tx_load_eval_keys.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p]
+        L.tx_load_round_luts.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.tx_load_ctr_luts.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.tx_transcipher.argtypes = [C.c_void_p, u8p, C.c_size_t, u8p, C.c_void_p, C.c_int]
+        L.tx_transcipher_partial.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_int, u64p]
+        L.tx_max_u16.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_stage_lwe_keyswitch.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_stage_blind_rotate.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_stage_extract_trace.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_stage_scheme_switch_fourier.argtypes = [C.c_void_p, u64p, C.c_size_t, f64p]
+        L.tx_stage_lut_eval.argtypes = [C.c_void_p, f64p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p]
+        L.tx_get_timing.argtypes = [C.c_void_p, C.POINTER(TxTiming)]
+        L.tx_get_twiddles.argtypes = [C.c_void_p, f64p]
+        _LIB = L
+    return _LIB
+
+
+def _p64(a): return a.ctypes.data_as(u64p)
+def _p8(a): return a.ctypes.data_as(u8p)
+def _pf(a): return a.ctypes.data_as(f64p)
+
+
+def aes_tight(n=768):
+    p = TxParams()
+    lib().tx_params_aes_tight(C.byref(p))
+    p.n = n
+    return p
+
+
+class Engine:
+    """One context on one GPU (tx_ctx)."""
+
+    def __init__(self, params=None, device=0):
+        L = lib()
+        self.p = params or aes_tight()
+        self.h = L.tx_create(C.byref(self.p), device)
+        if not self.h:
+            raise TxError(L.tx_last_error().decode())
+        self.K = self.p.k + 1
+        self.gl = self.K * self.p.N
+        self.big = self.p.k * self.p.N + 1
+        self.small = self.p.n + 1
+
+    def close(self):
+        if self.h:
+            lib().tx_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise TxError(lib().tx_last_error().decode())
+
+    def load_eval_keys(self, bsk, ksk, auto_keys, ss_key):
+        self._chk(lib().tx_load_eval_keys(self.h, _p64(bsk), _p64(ksk), _p64(auto_keys), _p64(ss_key)))
+
+    def load_round_luts(self, luts):
+        self._chk(lib().tx_load_round_luts(self.h, _p64(luts), luts.size))
+
+    def load_ctr_luts(self, luts):
+        self._chk(lib().tx_load_ctr_luts(self.h, _p64(luts), luts.size))
+
+    def transcipher(self, ct_bytes, iv=None, out_device_ptr=None):
+        ct = np.frombuffer(bytes(ct_bytes), np.uint8).copy()
+        nb = ct.size // 16
+        ivp = None
+        if iv is not None:
+            ivb = np.frombuffer(bytes(iv), np.uint8).copy()
+            ivp = _p8(ivb)
+        if out_device_ptr is not None:
+            self._chk(lib().tx_transcipher(self.h, _p8(ct), nb, ivp, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = np.zeros(nb * 128 * self.big, np.uint64)
+        self._chk(lib().tx_transcipher(self.h, _p8(ct), nb, ivp, out.ctypes.data_as(C.c_void_p), 0))
+        return out.reshape(nb * 128, self.big)
+
+    def transcipher_partial(self, ct_bytes, rounds_done):
+        ct = np.frombuffer(bytes(ct_bytes), np.uint8).copy()
+        nb = ct.size // 16
+        out = np.zeros(nb * 128 * self.big, np.uint64)
+        self._chk(lib().tx_transcipher_partial(self.h, _p8(ct), nb, rounds_done, _p64(out)))
+        return out.reshape(nb * 128, self.big)
+
+    def max_u16(self, lwe_bits):
+        lwe_bits = np.ascontiguousarray(lwe_bits, np.uint64)
+        nv = lwe_bits.size // (16 * self.big)
+        out = np.zeros(16 * self.big, np.uint64)
+        self._chk(lib().tx_max_u16(self.h, _p64(lwe_bits), nv, _p64(out)))
+        return out.reshape(16, self.big)
+
+    # ---- stage entry points ----
+    def lwe_keyswitch(self, lwe_big):
+        lwe_big = np.ascontiguousarray(lwe_big, np.uint64)
+        cnt = lwe_big.size // self.big
+        out = np.zeros(cnt * self.small, np.uint64)
+        self._chk(lib().tx_stage_lwe_keyswitch(self.h, _p64(lwe_big), cnt, _p64(out)))
+        return out.reshape(cnt, self.small)
+
+    def blind_rotate(self, lwe_small):
+        lwe_small = np.ascontiguousarray(lwe_small, np.uint64)
+        cnt = lwe_small.size // self.small
+        out = np.zeros(cnt * self.gl, np.uint64)
+        self._chk(lib().tx_stage_blind_rotate(self.h, _p64(lwe_small), cnt, _p64(out)))
+        return out.reshape(cnt, self.K, self.p.N)
+
+    def extract_trace(self, acc):
+        acc = np.ascontiguousarray(acc, np.uint64)
+        cnt = acc.size // self.gl
+        out = np.zeros(cnt * self.p.cbs_level * self.gl, np.uint64)
+        self._chk(lib().tx_stage_extract_trace(self.h, _p64(acc), cnt, _p64(out)))
+        return out.reshape(cnt, self.p.cbs_level, self.K, self.p.N)
+
+    def scheme_switch_fourier(self, glev):
+        glev = np.ascontiguousarray(glev, np.uint64)
+        cnt = glev.size // (self.p.cbs_level * self.gl)
+        out = np.zeros(cnt * self.p.cbs_level * self.K * self.gl, np.float64)
+        self._chk(lib().tx_stage_scheme_switch_fourier(self.h, _p64(glev), cnt, _pf(out)))
+        return out.reshape(cnt, self.p.cbs_level, self.K, self.K, self.p.N)
+
+    def lut_eval(self, ggsw_f, ctr, lut_set, nlut):
+        ggsw_f = np.ascontiguousarray(ggsw_f, np.float64)
+        nbytes = ggsw_f.size // (8 * self.p.cbs_level * self.K * self.gl)
+        out = np.zeros(nlut * nbytes * 8 * self.big, np.uint64)
+        self._chk(lib().tx_stage_lut_eval(self.h, _pf(ggsw_f), nbytes, int(ctr), lut_set, nlut, _p64(out)))
+        return out.reshape(nlut, nbytes * 8, self.big)
+
+    def timing(self):
+        t = TxTiming()
+        self._chk(lib().tx_get_timing(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in TxTiming._fields_}
+
+    def twiddles(self):
+        out = np.zeros(22 * 64 * 2, np.float64)
+        self._chk(lib().tx_get_twiddles(self.h, _pf(out)))
+        return out
