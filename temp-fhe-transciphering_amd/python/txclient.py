@@ -1,0 +1,93 @@
+"""ctypes binding of libtxclient.so (client side: key generation, keyed LUTs, decryption)."""
+import ctypes as C
+import os
+import numpy as np
+from txhip import TxParams, PKG_DIR, u64p, u8p
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(os.path.join(PKG_DIR, "libtxclient.so"))
+        for name in ("txc_bsk_words", "txc_ksk_words", "txc_auto_words", "txc_ss_words", "txc_lut_words", "txc_ctr_lut_words"):
+            getattr(L, name).restype = C.c_size_t
+            getattr(L, name).argtypes = [C.POINTER(TxParams)]
+        _LIB = L
+    return _LIB
+
+
+def _p64(a): return a.ctypes.data_as(u64p)
+def _p8(a): return a.ctypes.data_as(u8p)
+
+
+class ClientKeys:
+    """What client_key_generation writes: secret keys + the four evaluation keys (standard domain)."""
+
+    def __init__(self, p, seed):
+        L = lib()
+        self.p = p
+        self.lwe_sk = np.zeros(p.n, np.uint64)
+        self.glwe_sk = np.zeros(p.k * p.N, np.uint64)
+        self.bsk = np.zeros(L.txc_bsk_words(C.byref(p)), np.uint64)
+        self.ksk = np.zeros(L.txc_ksk_words(C.byref(p)), np.uint64)
+        self.auto = np.zeros(L.txc_auto_words(C.byref(p)), np.uint64)
+        self.ss = np.zeros(L.txc_ss_words(C.byref(p)), np.uint64)
+        rc = L.txc_keygen(C.byref(p), C.c_uint64(seed), _p64(self.lwe_sk), _p64(self.glwe_sk), _p64(self.bsk),
+                          _p64(self.ksk), _p64(self.auto), _p64(self.ss))
+        if rc:
+            raise RuntimeError("txc_keygen failed")
+
+    def round_luts(self, aes_key, seed):
+        luts = np.zeros(lib().txc_lut_words(C.byref(self.p)), np.uint64)
+        k = np.frombuffer(bytes(aes_key), np.uint8).copy()
+        lib().txc_make_round_luts(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk), _p64(luts))
+        return luts
+
+    def ctr_luts(self, aes_key, seed):
+        luts = np.zeros(lib().txc_ctr_lut_words(C.byref(self.p)), np.uint64)
+        k = np.frombuffer(bytes(aes_key), np.uint8).copy()
+        lib().txc_make_ctr_luts(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk), _p64(luts))
+        return luts
+
+    def decrypt_bits(self, lwe):
+        lwe = np.ascontiguousarray(lwe, np.uint64)
+        cnt = lwe.size // (self.p.k * self.p.N + 1)
+        bits = np.zeros(cnt, np.uint8)
+        lib().txc_decrypt_bits(C.byref(self.p), _p64(self.glwe_sk), _p64(lwe), C.c_size_t(cnt), _p8(bits))
+        return bits
+
+    def encrypt_bits(self, bits, seed):
+        bits = np.ascontiguousarray(bits, np.uint8)
+        out = np.zeros(bits.size * (self.p.k * self.p.N + 1), np.uint64)
+        lib().txc_encrypt_bits(C.byref(self.p), C.c_uint64(seed), _p64(self.glwe_sk), _p8(bits), C.c_size_t(bits.size), _p64(out))
+        return out.reshape(bits.size, -1)
+
+
+def bits_to_u16(bits):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(bits.size // 16, np.uint16)
+    lib().txc_bits_to_u16(_p8(bits), C.c_size_t(bits.size), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def aes_ecb_encrypt(key, data):
+    d = np.frombuffer(bytes(data), np.uint8).copy(); o = np.zeros_like(d)
+    k = np.frombuffer(bytes(key), np.uint8).copy()
+    lib().txc_aes128_ecb_encrypt(_p8(k), _p8(d), C.c_size_t(d.size // 16), _p8(o))
+    return bytes(o)
+
+
+def aes_ecb_decrypt(key, data):
+    d = np.frombuffer(bytes(data), np.uint8).copy(); o = np.zeros_like(d)
+    k = np.frombuffer(bytes(key), np.uint8).copy()
+    lib().txc_aes128_ecb_decrypt(_p8(k), _p8(d), C.c_size_t(d.size // 16), _p8(o))
+    return bytes(o)
+
+
+def aes_ctr_crypt(key, iv, data):
+    d = np.frombuffer(bytes(data), np.uint8).copy(); o = np.zeros_like(d)
+    k = np.frombuffer(bytes(key), np.uint8).copy(); v = np.frombuffer(bytes(iv), np.uint8).copy()
+    lib().txc_aes128_ctr_crypt(_p8(k), _p8(v), _p8(d), C.c_size_t(d.size), _p8(o))
+    return bytes(o)
