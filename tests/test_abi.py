@@ -1,0 +1,85 @@
+"""CPU tests of the drop-in boundary: the shared library loads without a GPU, exports every
+symbol declared in include/tfhe_mi355x.h, validates parameters, and fails loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tfhe_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import txhip
+    L = txhip.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/tfhe_mi355x.h but not exported"
+    assert set(txhip.EXPORTS) == set(syms)
+
+
+def test_client_library_exports():
+    import txclient
+    L = txclient.lib()
+    text = open(os.path.join(ROOT, "temp-fhe-transciphering_amd", "host", "txclient.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for s in set(re.findall(r"\b(txc_[a-z0-9_]+)\s*\(", text)):
+        assert hasattr(L, s)
+
+
+def test_params_match_aes_tight():
+    """tx_params_aes_tight mirrors cbs_lib/src/aes_instances.rs:76-97"""
+    import txhip
+    p = txhip.aes_tight()
+    assert (p.n, p.N, p.k) == (768, 1024, 2)
+    assert (p.pbs_base_log, p.pbs_level) == (23, 1)
+    assert (p.ks_base_log, p.ks_level, p.ks_N) == (4, 3, 256)
+    assert (p.auto_base_log, p.auto_level, p.auto_split) == (13, 3, 41)
+    assert (p.ss_base_log, p.ss_level) == (17, 2)
+    assert (p.cbs_base_log, p.cbs_level, p.log_lut_count) == (2, 7, 3)
+    assert abs(p.lwe_std - 7.0204746294012e-06) < 1e-18 and abs(p.glwe_std - 2.9403601535432533e-16) < 1e-28
+
+
+def test_create_rejects_foreign_parameters():
+    import txhip
+    p = txhip.aes_tight()
+    p.cbs_level = 6
+    with pytest.raises(txhip.TxError, match="AES_TIGHT"):
+        txhip.Engine(p, 0)
+    p = txhip.aes_tight(n=300)
+    with pytest.raises(txhip.TxError, match="multiple of 256"):
+        txhip.Engine(p, 0)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """on a box without a HIP device the product path must fail loudly, never route elsewhere"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import txhip
+    with pytest.raises(txhip.TxError, match="no CPU fallback"):
+        txhip.Engine(txhip.aes_tight(), 0)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "temp-fhe-transciphering_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".h", ".cpp", ".py", "Makefile")):
+                t = open(os.path.join(d, f)).read()
+                assert "txoracle" not in t and "oracle_lib" not in t and "libtxoracle" not in t, f
+
+
+def test_client_aes_and_bit_packing():
+    import txclient
+    key = bytes(range(16))
+    assert txclient.aes_ecb_encrypt(key, bytes.fromhex("00112233445566778899aabbccddeeff")).hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"
+    bits = np.array([1] + [0] * 15 + [0] * 15 + [1], np.uint8)
+    assert txclient.bits_to_u16(bits).tolist() == [0x8000, 1]

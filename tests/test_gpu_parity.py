@@ -1,0 +1,264 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every stage and the whole schedule, called through
+the C ABI, must equal the CPU oracle bit for bit on the same inputs (the kernels use the oracle's
+transform network and operation order), and full-size runs must decrypt bit-exact to cleartext AES
+(the reference's own acceptance criterion, harness/verify_result.py:31-42)."""
+import json
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "harness_fixtures.json")))
+AES_KEY = bytes.fromhex("dc937b59892604f5a86ac96936cd7ff0")
+AES_IV = bytes.fromhex("64b92e64992534e495b9da182409427c")
+
+
+def pack_u16(db):
+    return b"".join(int(v).to_bytes(2, "big") for v in db)
+
+
+class Rig:
+    """oracle keys + oracle context + GPU engine for one n"""
+
+    def __init__(self, n, seed):
+        import oracle_lib as O
+        import txhip
+        self.O = O
+        self.p = O.aes_tight(n=n)
+        self.keys = O.Keys(self.p, seed=seed)
+        self.octx = O.Ctx(self.keys)
+        self.eng = txhip.Engine(txhip.aes_tight(n=n), 0)
+        self.eng.load_eval_keys(self.keys.bsk, self.keys.ksk, self.keys.auto, self.keys.ss)
+        self.luts = self.keys.round_luts(AES_KEY)
+        self.ctr_luts = self.keys.ctr_luts(AES_KEY)
+        self.eng.load_round_luts(self.luts)
+        self.eng.load_ctr_luts(self.ctr_luts)
+
+    def close(self):
+        self.eng.close()
+        self.octx.close()
+
+
+@pytest.fixture(scope="module")
+def rig256():
+    r = Rig(256, 41)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def rig768():
+    r = Rig(768, 42)
+    yield r
+    r.close()
+
+
+def test_twiddle_tables_identical(rig256):
+    import ctypes as C
+    O = rig256.O
+    t = np.ctypeslib.as_array(O.lib().txo_twiddles_1024(), shape=(22 * 64 * 2,))
+    assert np.array_equal(rig256.eng.twiddles(), t)
+
+
+@pytest.mark.parametrize("which", ["rig256", "rig768"])
+def test_stages_bit_identical_to_oracle(which, request):
+    r = request.getfixturevalue(which)
+    O, eng, octx, p, keys = r.O, r.eng, r.octx, r.p, r.keys
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, 16).astype(np.uint8)
+    ct = O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=9)
+    # a4
+    s_g, s_o = eng.lwe_keyswitch(ct), octx.lwe_keyswitch(ct)
+    assert np.array_equal(s_g, s_o)
+    # a5 (also an all-zero mask element: pbs.rs:111 skip path, and extreme bodies)
+    s_in = s_o.copy()
+    s_in[0, 3] = 0
+    s_in[1, p.n] = np.uint64(2**64 - 1)
+    s_in[2, p.n] = 0
+    a_g, a_o = eng.blind_rotate(s_in), octx.blind_rotate(s_in)
+    assert np.array_equal(a_g, a_o)
+    # a6 + a7
+    g_g, g_o = eng.extract_trace(a_o[:4]), octx.extract_trace(a_o[:4])
+    assert np.array_equal(g_g, g_o)
+    # a8 + a9
+    f_g = eng.scheme_switch_fourier(g_o)
+    f_o = octx.ggsw_to_fourier(octx.scheme_switch(g_o))
+    assert np.array_equal(f_g, f_o)
+
+
+def test_lut_eval_bit_identical_and_correct(rig256):
+    r = rig256
+    O, eng, octx, p, keys = r.O, r.eng, r.octx, r.p, r.keys
+    xs = [0x00, 0xFF, 0xA7]
+    bits = np.array([(x >> i) & 1 for x in xs for i in range(8)], np.uint8)
+    ct = O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=10)
+    gf = octx.circuit_bootstrap(ct)
+    gl = octx.gl
+    for (ctr, st, nlut, blob, mults) in [(0, 2, 4, r.luts, 4), (0, 9, 1, r.luts, 4), (1, 4, 3, r.ctr_luts, 3)]:
+        out_g = eng.lut_eval(gf, ctr, st, nlut)
+        out_o = octx.lut_eval(gf, blob[st * mults * 16 * 2 * gl:], nlut, 2 * gl, 16 * 2 * gl)
+        assert np.array_equal(out_g, out_o)
+
+
+def test_partial_schedule_bit_identical_n256(rig256):
+    """rounds 10/9 + two bootstrapped rounds of two blocks, ciphertext-level equality"""
+    r = rig256
+    ct = bytes(range(32))
+    for rounds in (0, 2):
+        assert np.array_equal(r.eng.transcipher_partial(ct, rounds), r.octx.transcipher_partial(r.luts, ct, rounds))
+
+
+def test_partial_schedule_bit_identical_full_parameters(rig768):
+    r = rig768
+    ct = bytes(range(16, 32))
+    assert np.array_equal(r.eng.transcipher_partial(ct, 1), r.octx.transcipher_partial(r.luts, ct, 1))
+
+
+def test_toy_instance_full_cipher_matches_oracle_and_cleartext(rig768):
+    """BASELINE config 1 at full parameters: ciphertext-level parity and plaintext exactness"""
+    r = rig768
+    fx = [f for f in FIX if f["size"] == 0 and f["dataset_seed"] == 123][0]
+    ct = bytes.fromhex(fx["db_hex"])
+    out = r.eng.transcipher(ct)
+    assert np.array_equal(out, r.octx.transcipher(r.luts, ct))
+    assert r.O.bits_msb_to_bytes(r.O.lwe_decrypt_bits(r.keys.glwe_sk, out)) == pack_u16(fx["db"])
+
+
+def test_small_instance_sbox_layer_only(rig768):
+    """BASELINE config 2: small instance (8 blocks), batched PBS S-box only: after the first
+    bootstrapped round the state decrypts to InvMixColumns(InvSubBytes(..)^rk8) of cleartext AES"""
+    r = rig768
+    O = r.O
+    fx = [f for f in FIX if f["size"] == 1 and f["dataset_seed"] == 123][0]
+    rk = O.aes_expand(AES_KEY)
+    pt = pack_u16(fx["db"])
+    ct = b"".join(O.aes_encrypt_block(rk, pt[i:i + 16]) for i in range(0, len(pt), 16))
+    st = r.eng.transcipher_partial(ct, 1)
+    got = O.lwe_decrypt_bits(r.keys.glwe_sk, st).reshape(-1, 8)
+    got_bytes = bytes((got * (1 << np.arange(8))).sum(axis=1).astype(np.uint8))      # LSB-first state
+    # cleartext: state entering round 7's InvSubBytes = after ARK10,[ISR,ISB,ARK9,IMC],[ISR,ISB,ARK8,IMC],ISR
+    rkm = rk.reshape(11, 16)
+
+    def isr(s):
+        return bytes(s[4 * ((4 + c - rr) % 4) + rr] for c in range(4) for rr in range(4))
+
+    def gm(a, b):
+        x = 0
+        for _ in range(8):
+            if b & 1:
+                x ^= a
+            a = ((a << 1) ^ 0x1B) & 0xFF if a & 0x80 else a << 1
+            b >>= 1
+        return x
+
+    inv = [0] * 256
+    sbox = [0] * 256
+    for x in range(256):
+        y = 0
+        if x:
+            y = next(v for v in range(1, 256) if gm(x, v) == 1)
+        rr, s = y, y
+        for _ in range(4):
+            rr = ((rr << 1) | (rr >> 7)) & 0xFF
+            s ^= rr
+        sbox[x] = s ^ 0x63
+    for x in range(256):
+        inv[sbox[x]] = x
+
+    def imc(s):
+        o = bytearray(16)
+        for c in range(4):
+            for rr in range(4):
+                o[4 * c + rr] = gm(s[4 * c + rr], 14) ^ gm(s[4 * c + (rr + 1) % 4], 11) ^ gm(s[4 * c + (rr + 2) % 4], 13) ^ gm(s[4 * c + (rr + 3) % 4], 9)
+        return bytes(o)
+
+    exp = b""
+    for i in range(0, len(ct), 16):
+        s = bytes(a ^ b for a, b in zip(ct[i:i + 16], rkm[10]))
+        for rnd in (9, 8):
+            s = isr(s)
+            s = bytes(inv[v] ^ k for v, k in zip(s, rkm[rnd]))
+            s = imc(s)
+        exp += isr(s)
+    assert got_bytes == exp
+
+
+def test_medium_instance_ctr_fixture_decrypts_exactly(rig768):
+    """BASELINE config 3 on the harness's own medium data (CTR, golden fixture): 64 blocks"""
+    r = rig768
+    fx = [f for f in FIX if f["size"] == 2 and f["dataset_seed"] == 123][0]
+    out = r.eng.transcipher(bytes.fromhex(fx["db_hex"]), iv=AES_IV)
+    bits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, out)
+    vals = (bits.reshape(-1, 16) * (1 << np.arange(15, -1, -1))).sum(axis=1)
+    assert vals.tolist() == fx["db"]                       # verify_aes_decryption.py semantics
+    assert int(vals.max()) == fx["max_value"]
+
+
+def test_medium_instance_ecb_schedule_decrypts_exactly(rig768):
+    """the reference's own schedule on 64 blocks, plus properties that do not need the oracle:
+    block independence (a batch equals its blocks run alone) and determinism"""
+    r = rig768
+    O = r.O
+    fx = [f for f in FIX if f["size"] == 2 and f["dataset_seed"] == 7][0]
+    rk = O.aes_expand(AES_KEY)
+    pt = pack_u16(fx["db"])
+    ct = b"".join(O.aes_encrypt_block(rk, pt[i:i + 16]) for i in range(0, len(pt), 16))
+    out = r.eng.transcipher(ct)
+    assert O.bits_msb_to_bytes(O.lwe_decrypt_bits(r.keys.glwe_sk, out)) == pt
+    alone = r.eng.transcipher(ct[16 * 37:16 * 38])
+    assert np.array_equal(alone, out[128 * 37:128 * 38])
+    assert np.array_equal(r.eng.transcipher(ct[:48]), out[:128 * 3])          # ragged batch of 3
+
+
+def test_max_of_toy_dataset(rig768):
+    """mini-workload 0 (verify_result.py on max_value.txt): max of the 8 transciphered u16"""
+    r = rig768
+    fx = [f for f in FIX if f["size"] == 0 and f["dataset_seed"] == 7][0]
+    out = r.eng.transcipher(bytes.fromhex(fx["db_hex"]))
+    mx = r.eng.max_u16(out)
+    dec = r.O.lwe_decrypt_bits(r.keys.glwe_sk, mx)
+    assert int("".join(str(int(b)) for b in dec), 2) == fx["max_value"]
+    assert np.array_equal(mx, r.octx.max_u16(out, tournament=True))
+
+
+def test_max_handles_equal_operands_and_odd_counts(rig256):
+    r = rig256
+    vals = [7, 0xBEEF, 0xBEEF, 3, 0x8000]
+    bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+    ct = r.O.lwe_encrypt_bits(r.p, r.keys.glwe_sk, bits, r.p.glwe_std, seed=12)
+    mx = r.eng.max_u16(ct)
+    dec = r.O.lwe_decrypt_bits(r.keys.glwe_sk, mx)
+    assert int("".join(str(int(b)) for b in dec), 2) == 0xBEEF
+    assert np.array_equal(mx, r.octx.max_u16(ct, tournament=True))
+
+
+def test_edge_cases_and_errors(rig256):
+    import txhip
+    r = rig256
+    assert r.eng.transcipher(b"").shape[0] == 0                       # empty input
+    e2 = txhip.Engine(txhip.aes_tight(n=256), 0)
+    with pytest.raises(txhip.TxError, match="keys not loaded"):
+        e2.transcipher(bytes(16))
+    e2.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    with pytest.raises(txhip.TxError, match="LUTs not loaded"):
+        e2.transcipher(bytes(16))
+    with pytest.raises(txhip.TxError, match="wrong size"):
+        e2.load_round_luts(r.luts[:-1])
+    e2.close()
+
+
+def test_client_library_keys_end_to_end(rig256):
+    """product-only path: client lib keygen -> GPU transcipher -> client lib decrypt"""
+    import txhip
+    import txclient
+    p = txhip.aes_tight(n=256)
+    ck = txclient.ClientKeys(p, seed=1234)
+    eng = txhip.Engine(p, 0)
+    eng.load_eval_keys(ck.bsk, ck.ksk, ck.auto, ck.ss)
+    eng.load_round_luts(ck.round_luts(AES_KEY, seed=5))
+    fx = [f for f in FIX if f["size"] == 0 and f["dataset_seed"] == 123][0]
+    out = eng.transcipher(bytes.fromhex(fx["db_hex"]))
+    assert txclient.bits_to_u16(ck.decrypt_bits(out)).tolist() == fx["db"]
+    eng.close()

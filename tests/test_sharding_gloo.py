@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the block-sharding + gather logic (txdist), with the
+oracle standing in for the per-rank GPU engine (the tests may use the oracle; the product may not)."""
+import json
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_shard_covers_every_block_once():
+    sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
+    import txdist
+    for n in (0, 1, 3, 8, 64, 65):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for r in range(world):
+                s, c = txdist.shard(n, world, r)
+                seen += list(range(s, s + c))
+            assert seen == list(range(n))
+    assert txdist.iv_add(bytes([0xFF] * 16), 1) == bytes(16)
+    assert txdist.iv_add(bytes(15) + b"\xff", 1) == bytes(14) + b"\x01\x00"
+
+
+def _worker(rank, world, port, mode, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import txdist
+    fx = [f for f in json.load(open(os.path.join(HERE, "golden", "harness_fixtures.json")))
+          if f["size"] == 1 and f["dataset_seed"] == 123][0]
+    key, iv = bytes.fromhex(fx["aes_key"]), bytes.fromhex(fx["aes_iv"])
+    p = O.aes_tight(n=256)
+    keys = O.Keys(p, seed=33)                       # same seed on both ranks: identical key replicas
+    ctx = O.Ctx(keys, threads=4)
+    nb = 3                                          # ragged: rank 0 gets 2 blocks, rank 1 gets 1
+    pt = b"".join(int(v).to_bytes(2, "big") for v in fx["db"][: 8 * nb])
+    if mode == "ctr":
+        ct, luts, ivv = bytes.fromhex(fx["db_hex"])[: 16 * nb], keys.ctr_luts(key), iv
+    else:
+        rk = O.aes_expand(key)
+        ct, luts, ivv = b"".join(O.aes_encrypt_block(rk, pt[i:i + 16]) for i in range(0, len(pt), 16)), keys.round_luts(key), None
+
+    def local_fn(ct_slab, iv_slab, n_local, n_pad):
+        out = torch.zeros((n_pad * 128, ctx.big), dtype=torch.int64)
+        if n_local:
+            r = ctx.transcipher_ctr(luts, iv_slab, ct_slab) if mode == "ctr" else ctx.transcipher(luts, ct_slab)
+            out[: n_local * 128] = torch.from_numpy(r.view(np.int64))
+        return out
+
+    res = txdist.transcipher_sharded(local_fn, ct, ivv, rank, world, dist)
+    if rank == 0:
+        bits = O.lwe_decrypt_bits(keys.glwe_sk, res.numpy().view(np.uint64))
+        q.put(O.bits_msb_to_bytes(bits) == pt)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ctr"])
+def test_two_rank_sharded_transcipher_gloo(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert ok
