@@ -106,6 +106,13 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     memset(&c->timing, 0, sizeof c->timing);
     if (hipStreamCreate(&c->stream) != hipSuccess) { fail("tx_create: hipStreamCreate failed"); delete c; return nullptr; }
     if (upload_tables(c) != 0) { delete c; return nullptr; }
+    // the trace kernels park two polynomials per wave in LDS: more than the 64 KiB default
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TRACE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TRACE) != hipSuccess) {
+        fail("tx_create: cannot reserve LDS for the trace kernels"); delete c; return nullptr;
+    }
     return c;
 }
 
@@ -283,7 +290,7 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {
     ev_begin(c, F_TRACE);
-    hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, acc, glev,
+    hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TRACE, c->stream, acc, glev,
                        (int)count, c->auto_f, c->auto_split_stride, c->tw);
     ev_end(c);
 }

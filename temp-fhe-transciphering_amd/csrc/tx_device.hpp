@@ -138,6 +138,95 @@ __device__ __forceinline__ void fft_inv(cplx (&v)[8], const cplx *tw, cplx *tile
     for (int m = 0; m < 8; m++) v[m] = cmulc(v[m], tw[m * 64 + lane]);
 }
 
+
+// P polynomials transformed together: the twiddles of a pass are loaded once (batched, so the
+// LDS reads are all in flight before the first use) and the P tile round trips are issued back to
+// back on the same tile -- the LDS unit executes one wave's DS instructions in order, so poly p+1's
+// tile writes cannot overtake poly p's tile reads -- which lets butterflies of one polynomial
+// cover the LDS latency of the next.  Arithmetic per polynomial is identical to fft_fwd/fft_inv.
+template <int P>
+__device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)
+{
+    {
+        cplx w[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], w[m]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<+1>(v[p]);
+    {
+        cplx w[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], w[r - 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) xchg_hi(v[p], tile, lane);
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<+1>(v[p]);
+    {
+        cplx w[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], w[r - 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) xchg_lo(v[p], tile, lane);
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<+1>(v[p]);
+}
+template <int P>
+__device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)
+{
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
+#pragma unroll
+    for (int p = 0; p < P; p++) xchg_lo(v[p], tile, lane);
+    {
+        cplx w[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r - 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
+#pragma unroll
+    for (int p = 0; p < P; p++) xchg_hi(v[p], tile, lane);
+    {
+        cplx w[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r - 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
+    {
+        cplx w[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[p][m] = cmulc(v[p][m], w[m]);
+    }
+}
+
 // round-half-even(x) mod 2^64 in 7 f64 operations + 1 integer add3 (oracle f64_to_torus)
 __device__ __forceinline__ uint64_t f64_to_torus(double x)
 {
@@ -201,6 +290,24 @@ __device__ __forceinline__ uint64_t rot_read(const uint64_t *s, int j, int rot)
     if (src < 0) { src += N; neg = ~neg; }
     uint64_t x = s[src];
     return (x ^ neg) - neg;
+}
+
+
+// all 16 coefficients of this lane of  s(X) * X^rot - own[], reads issued together
+__device__ __forceinline__ void rot_sub16(const uint64_t *s, const uint64_t (&own)[16], int rot, int lane, uint64_t (&out)[16])
+{
+    uint64_t x[16], neg[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int src = lane + 64 * m - rot;
+        uint64_t ng = 0;
+        if (src < 0) { src += N; ng = ~ng; }
+        if (src < 0) { src += N; ng = ~ng; }
+        x[m] = s[src];
+        neg[m] = ng;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[m] = ((x[m] ^ neg[m]) - neg[m]) - own[m];
 }
 
 }  // namespace txd

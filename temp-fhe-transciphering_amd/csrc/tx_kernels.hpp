@@ -33,7 +33,8 @@ struct WaveCtx {
 
 // loads the twiddle table into LDS; returns the per-wave context.  Contains the only
 // workgroup-wide barrier of every kernel.
-__device__ __forceinline__ WaveCtx wave_setup(const cplx *tw_g, unsigned char *lds)
+__device__ __forceinline__ WaveCtx wave_setup(const cplx *tw_g, unsigned char *lds,
+                                              size_t wave_bytes = SCRATCH_CPLX * sizeof(cplx))
 {
     cplx *tw = reinterpret_cast<cplx *>(lds);
     for (int i = threadIdx.x; i < TW_ROWS * 64; i += blockDim.x) tw[i] = tw_g[i];
@@ -41,7 +42,7 @@ __device__ __forceinline__ WaveCtx wave_setup(const cplx *tw_g, unsigned char *l
     WaveCtx w;
     int wave = threadIdx.x >> 6;
     w.tw = tw;
-    w.tile = tw + TW_ROWS * 64 + wave * SCRATCH_CPLX;
+    w.tile = reinterpret_cast<cplx *>(lds + TW_ROWS * 64 * sizeof(cplx) + wave * wave_bytes);
     w.pl = reinterpret_cast<uint64_t *>(w.tile);
     w.lane = threadIdx.x & 63;
     w.unit = blockIdx.x * WAVES + wave;
@@ -70,10 +71,60 @@ __device__ __forceinline__ void fmac8(cplx (&acc)[8], const cplx (&d)[8], const 
     }
 }
 
+__device__ __forceinline__ void load_key8(cplx (&g)[8], const cplx *key, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) g[r] = key[r * 64 + lane];
+}
+__device__ __forceinline__ void fmac8r(cplx (&acc)[8], const cplx (&d)[8], const cplx (&g)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        double re = acc[r].x, im = acc[r].y;
+        re = __builtin_fma(d[r].x, g[r].x, re);
+        re = __builtin_fma(-d[r].y, g[r].y, re);
+        im = __builtin_fma(d[r].x, g[r].y, im);
+        im = __builtin_fma(d[r].y, g[r].x, im);
+        acc[r] = make_double2(re, im);
+    }
+}
+
+// P consecutive decomposition levels (finest of the group first) of one row: digits -> f64,
+// transformed together, then accumulated against the key: F[c] += D[i] * key[lev(i)][c], for fixed c
+// in increasing i (the oracle's order: row outer, level finest-first inner).  Key loads are
+// software-pipelined one polynomial ahead.  lev0 = level index (0 = level 1) of the group's first digit.
+template <int B, int L, int P, int NCOL, typename ST>
+__device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], ST (&shi)[8], int lev0,
+                                              const cplx *key, size_t lev_stride, size_t col_stride, const WaveCtx &w)
+{
+    typedef Decomp<B, L> D;
+    cplx d[P][8];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
+    cplx g[8];
+    load_key8(g, key + (size_t)lev0 * lev_stride, w.lane);
+    fft_fwd_n<P>(d, w.tw, w.tile, w.lane);
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int c = 0; c < NCOL; c++) {
+            cplx gn[8];
+            const bool last = (i == P - 1) && (c == NCOL - 1);
+            const int ni = (c + 1 < NCOL) ? i : i + 1, nc = (c + 1 < NCOL) ? c + 1 : 0;
+            if (!last) load_key8(gn, key + (size_t)(lev0 - ni) * lev_stride + (size_t)nc * col_stride, w.lane);
+            fmac8r(F[c], d[i], g);
+            if (!last) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) g[r] = gn[r];
+            }
+        }
+}
+
 // One row of an external product: decompose the 16 coefficients of this lane (lo[m] = coeff
-// t+64m, hi[m] = coeff t+64m+512), level L (finest) first, transform each digit polynomial and
-// accumulate it against the key row.  key points at GGSW element [lev 0][row r][col 0];
-// lev_stride / col_stride in complex units.  NCOL output columns.
+// t+64m, hi[m] = coeff t+64m+512), level L (finest) first, in groups of up to 3 levels.
+// key points at GGSW element [lev 0][row r][col 0]; strides in complex units.
 template <int B, int L, int NCOL>
 __device__ __forceinline__ void extprod_row(cplx (&F)[NCOL][8], const uint64_t (&lo)[8], const uint64_t (&hi)[8],
                                             const cplx *key, size_t lev_stride, size_t col_stride, const WaveCtx &w)
@@ -82,16 +133,15 @@ __device__ __forceinline__ void extprod_row(cplx (&F)[NCOL][8], const uint64_t (
     typename D::state_t slo[8], shi[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) { slo[m] = D::init(lo[m]); shi[m] = D::init(hi[m]); }
+    constexpr int G3 = L / 3, REM = L % 3;
+    int lev = L - 1;
 #pragma unroll 1
-    for (int i = 0; i < L; i++) {
-        const int lev = L - 1 - i;
-        cplx v[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) v[m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
-        fft_fwd(v, w.tw, w.tile, w.lane);
-#pragma unroll
-        for (int c = 0; c < NCOL; c++) fmac8(F[c], v, key + lev * lev_stride + c * col_stride, w.lane);
+    for (int gidx = 0; gidx < G3; gidx++) {
+        extprod_group<B, L, 3, NCOL>(F, slo, shi, lev, key, lev_stride, col_stride, w);
+        lev -= 3;
     }
+    if (REM == 2) extprod_group<B, L, 2, NCOL>(F, slo, shi, lev, key, lev_stride, col_stride, w);
+    if (REM == 1) extprod_group<B, L, 1, NCOL>(F, slo, shi, lev, key, lev_stride, col_stride, w);
 }
 
 // inverse-transform a Fourier accumulator and add the rounded result into 16 torus words
@@ -100,6 +150,15 @@ __device__ __forceinline__ void inv_add(cplx (&F)[8], uint64_t (&p)[16], const W
     fft_inv(F, w.tw, w.tile, w.lane);
 #pragma unroll
     for (int m = 0; m < 8; m++) { p[m] += f64_to_torus(F[m].x); p[m + 8] += f64_to_torus(F[m].y); }
+}
+// the three accumulators of a GLWE together
+__device__ __forceinline__ void inv_add3(cplx (&F)[KP][8], uint64_t (&p)[KP][16], const WaveCtx &w)
+{
+    fft_inv_n<KP>(F, w.tw, w.tile, w.lane);
+#pragma unroll
+    for (int c = 0; c < KP; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) { p[c][m] += f64_to_torus(F[c][m].x); p[c][m + 8] += f64_to_torus(F[c][m].y); }
 }
 
 template <int NCOL>
@@ -310,28 +369,47 @@ __global__ __launch_bounds__(256) void k_blind_rotate(const uint64_t *lwe, uint6
             acc[2][m] = (x ^ neg) - neg;
         }
     }
+    typedef Decomp<PBS_B, PBS_L> D;
+    cplx g[8];
+    load_key8(g, bsk_f, lane);                              // key polynomial (step 0, row 0, col 0)
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
-        const uint64_t a = ct[i];
-        if (a == 0) continue;                               // pbs.rs:111
-        const int rot = (int)modswitch(a);
-        cplx F[KP][8];
-        zero_f(F);
+        // a mask element equal to 0 (skipped at pbs.rs:111) rotates by 0: ct1 = 0 and the step adds 0
+        const int rot = (int)modswitch(ct[i]);
+        // ct1 = acc * X^rot - acc (pbs.rs:125-134), one-level decomposition, digits as f64
+        cplx d[KP][8];
 #pragma unroll
         for (int q = 0; q < KP; q++) {
-            // ct1 = acc * X^rot - acc     (pbs.rs:125-134)
             poly_to_lds(acc[q], w.pl, lane);
-            uint64_t lo[8], hi[8];
+            uint64_t diff[16];
+            rot_sub16(w.pl, acc[q], rot, lane, diff);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                lo[m] = rot_read(w.pl, lane + 64 * m, rot) - acc[q][m];
-                hi[m] = rot_read(w.pl, lane + 64 * m + 512, rot) - acc[q][m + 8];
+                D::state_t s0 = D::init(diff[m]), s1 = D::init(diff[m + 8]);
+                d[q][m] = make_double2((double)D::next(s0), (double)D::next(s1));
             }
-            const cplx *key = bsk_f + ((size_t)i * PBS_L * KP + q) * KP * H;
-            extprod_row<PBS_B, PBS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
         }
+        fft_fwd_n<KP>(d, w.tw, w.tile, lane);
+        const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
+        const int inext = (i + 1 < n) ? i + 1 : i;
 #pragma unroll
-        for (int c = 0; c < KP; c++) inv_add(F[c], acc[c], w);
+        for (int c = 0; c < KP; c++) {
+            cplx F[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) F[r] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < KP; q++) {
+                cplx gn[8];
+                const cplx *nk = (q + 1 < KP) ? row + ((size_t)(q + 1) * KP + c) * H
+                               : (c + 1 < KP) ? row + (size_t)(c + 1) * H
+                                              : bsk_f + (size_t)inext * KP * KP * H;
+                load_key8(gn, nk, lane);
+                fmac8r(F, d[q], g);
+#pragma unroll
+                for (int r = 0; r < 8; r++) g[r] = gn[r];
+            }
+            inv_add(F, acc[c], w);
+        }
     }
     uint64_t *o = acc_out + (size_t)w.unit * GL;
 #pragma unroll
@@ -346,68 +424,70 @@ __global__ __launch_bounds__(256) void k_blind_rotate(const uint64_t *lwe, uint6
 // switch with the 41/23-bit split key)   (ggsw_conv.rs:304-316, automorphism.rs:134-233,
 // fourier_glwe_keyswitch.rs:213-342).  auto_f: [split 2][idx 10][q 2][lev 3][col 3][512].
 // ------------------------------------------------------------------------------------------
-// scatter polynomial p (registers) to X -> X^t in LDS, read it back in natural order
-__device__ __forceinline__ void automorph(const uint64_t (&p)[16], uint64_t (&o)[16], uint32_t t, const WaveCtx &w)
+// LDS of the trace kernels: twiddles, then per wave: transpose tile + two parked polynomials
+constexpr size_t TRACE_WAVE_BYTES = SCRATCH_CPLX * sizeof(cplx) + 2 * N * sizeof(uint64_t);
+constexpr size_t LDS_BYTES_TRACE = TW_ROWS * 64 * sizeof(cplx) + WAVES * TRACE_WAVE_BYTES;
+
+// scatter polynomial p (registers) as p(X^t) into `dst` (LDS, natural order)
+__device__ __forceinline__ void automorph_to_lds(const uint64_t (&p)[16], uint64_t *dst, uint32_t t, int lane)
 {
     wave_lds_fence();
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-        uint32_t i = w.lane + 64 * m;
+        uint32_t i = lane + 64 * m;
         uint32_t it = i * t;
         uint64_t neg = (uint64_t)0 - (uint64_t)((it >> LOGN) & 1);
-        w.pl[it & (N - 1)] = (p[m] ^ neg) - neg;
+        dst[it & (N - 1)] = (p[m] ^ neg) - neg;
     }
     wave_lds_fence();
-#pragma unroll
-    for (int m = 0; m < 16; m++) o[m] = w.pl[w.lane + 64 * m];
 }
 
-// one trace on the GLWE held in g[3][16]
-__device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *auto_f, size_t split_stride, const WaveCtx &w)
+// one trace on the GLWE held in g[3][16]: for i = 1..10, t = N/2^(i-1)+1: g += KS_t(g(X^t)).
+// The key switch runs once per key split (low 41 bits, high 23 bits), re-deriving the digit
+// transforms from the permuted mask kept in LDS, so that only three Fourier accumulators are live.
+__device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *auto_f, size_t split_stride,
+                                           uint64_t *park, const WaveCtx &w)
 {
+    typedef Decomp<AUTO_B, AUTO_L> D;
 #pragma unroll 1
     for (int idx = 0; idx < LOGN; idx++) {
         const uint32_t t = (N >> idx) + 1;
-        cplx F[2][KP][8];
-        zero_f(F[0]); zero_f(F[1]);
+        automorph_to_lds(g[0], park, t, w.lane);
+        automorph_to_lds(g[1], park + N, t, w.lane);
+        {   // body: g[2] += g[2](X^t)   (keyswitch output starts as (0, 0, permuted body))
+            automorph_to_lds(g[2], w.pl, t, w.lane);
+            uint64_t pb[16];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            uint64_t pw[16];
-            automorph(g[q], pw, t, w);
-            typedef Decomp<AUTO_B, AUTO_L> D;
-            D::state_t slo[8], shi[8];
+            for (int m = 0; m < 16; m++) pb[m] = w.pl[w.lane + 64 * m];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { slo[m] = D::init(pw[m]); shi[m] = D::init(pw[m + 8]); }
-#pragma unroll 1
-            for (int i = 0; i < AUTO_L; i++) {
-                const int lev = AUTO_L - 1 - i;
-                cplx v[8];
-#pragma unroll
-                for (int m = 0; m < 8; m++) v[m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
-                fft_fwd(v, w.tw, w.tile, w.lane);
-                const cplx *key = auto_f + ((((size_t)idx * 2 + q) * AUTO_L) + lev) * KP * H;
-#pragma unroll
-                for (int s = 0; s < 2; s++)
-#pragma unroll
-                    for (int c = 0; c < KP; c++) fmac8(F[s][c], v, key + s * split_stride + c * H, w.lane);
-            }
+            for (int m = 0; m < 16; m++) g[2][m] += pb[m];
+            wave_lds_fence();
         }
-        // g += KS(g(X^t)) = (0, 0, body(X^t)) + lo + 2^41 hi
-        uint64_t pb[16];
-        automorph(g[2], pb, t, w);
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            cplx F[KP][8];
+            zero_f(F);
+#pragma unroll 1
+            for (int q = 0; q < 2; q++) {
+                const uint64_t *pw = park + q * N;
+                uint64_t x[16];
 #pragma unroll
-        for (int c = 0; c < KP; c++) {
-            uint64_t lo[16], hi[16];
+                for (int m = 0; m < 16; m++) x[m] = pw[w.lane + 64 * m];
+                D::state_t slo[8], shi[8];
 #pragma unroll
-            for (int m = 0; m < 16; m++) { lo[m] = 0; hi[m] = 0; }
-            inv_add(F[0][c], lo, w);
-            inv_add(F[1][c], hi, w);
-#pragma unroll
-            for (int m = 0; m < 16; m++) {
-                uint64_t ks = lo[m] + (hi[m] << AUTO_SPLIT);
-                if (c == KP - 1) ks += pb[m];
-                g[c][m] += ks;
+                for (int m = 0; m < 8; m++) { slo[m] = D::init(x[m]); shi[m] = D::init(x[m + 8]); }
+                const cplx *key = auto_f + (size_t)s * split_stride + (((size_t)idx * 2 + q) * AUTO_L) * KP * H;
+                extprod_group<AUTO_B, AUTO_L, AUTO_L, KP>(F, slo, shi, AUTO_L - 1, key, (size_t)KP * H, H, w);
             }
+            fft_inv_n<KP>(F, w.tw, w.tile, w.lane);
+            const int sh = s ? AUTO_SPLIT : 0;
+#pragma unroll
+            for (int c = 0; c < KP; c++)
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    g[c][m] += f64_to_torus(F[c][m].x) << sh;
+                    g[c][m + 8] += f64_to_torus(F[c][m].y) << sh;
+                }
         }
     }
 }
@@ -416,7 +496,8 @@ __global__ __launch_bounds__(256) void k_extract_trace(const uint64_t *acc, uint
                                                        const cplx *auto_f, size_t split_stride, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    WaveCtx w = wave_setup(tw_g, lds);
+    WaveCtx w = wave_setup(tw_g, lds, TRACE_WAVE_BYTES);
+    uint64_t *park = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
     if (w.unit >= count * CBS_L) return;
     const int ctx = w.unit / CBS_L, lvl = w.unit % CBS_L;         // lvl = level - 1 = rotation k
     const uint64_t *a = acc + (size_t)ctx * GL;
@@ -435,7 +516,7 @@ __global__ __launch_bounds__(256) void k_extract_trace(const uint64_t *acc, uint
 #pragma unroll
     for (int m = 0; m < 16; m++) g[2][m] = 0;
     if (lane == 0) g[2][0] = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
-    trace_regs(g, auto_f, split_stride, w);
+    trace_regs(g, auto_f, split_stride, park, w);
     uint64_t *o = glev + (size_t)w.unit * GL;
 #pragma unroll
     for (int q = 0; q < KP; q++)
@@ -448,7 +529,8 @@ __global__ __launch_bounds__(256) void k_trace(uint64_t *glwe, int count, const 
                                                const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    WaveCtx w = wave_setup(tw_g, lds);
+    WaveCtx w = wave_setup(tw_g, lds, TRACE_WAVE_BYTES);
+    uint64_t *park = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
     if (w.unit >= count) return;
     uint64_t *p = glwe + (size_t)w.unit * GL;
     uint64_t g[KP][16];
@@ -456,7 +538,7 @@ __global__ __launch_bounds__(256) void k_trace(uint64_t *glwe, int count, const 
     for (int q = 0; q < KP; q++)
 #pragma unroll
         for (int m = 0; m < 16; m++) g[q][m] = p[q * N + w.lane + 64 * m];
-    trace_regs(g, auto_f, split_stride, w);
+    trace_regs(g, auto_f, split_stride, park, w);
 #pragma unroll
     for (int q = 0; q < KP; q++)
 #pragma unroll
@@ -468,14 +550,19 @@ __global__ __launch_bounds__(256) void k_trace(uint64_t *glwe, int count, const 
 // (ggsw_conv.rs:163-193, SRV_AES:430-436).  Unit = (ciphertext, level).
 // ss_f: [i 2][lev 2][row 3][col 3][512];  out: [unit][row 3][col 3][512] complex.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_fourier_scaled(const uint64_t (&p)[16], cplx *o, const WaveCtx &w)
+// three torus polynomials -> Fourier, scaled by 2/N, stored at o + c * H
+__device__ __forceinline__ void store_fourier_scaled3(const uint64_t (&p)[KP][16], cplx *o, const WaveCtx &w)
 {
-    cplx v[8];
+    cplx v[KP][8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = make_double2(torus_to_f64(p[m]), torus_to_f64(p[m + 8]));
-    fft_fwd(v, w.tw, w.tile, w.lane);
+    for (int c = 0; c < KP; c++)
 #pragma unroll
-    for (int r = 0; r < 8; r++) o[r * 64 + w.lane] = make_double2(v[r].x * 0x1p-9, v[r].y * 0x1p-9);
+        for (int m = 0; m < 8; m++) v[c][m] = make_double2(torus_to_f64(p[c][m]), torus_to_f64(p[c][m + 8]));
+    fft_fwd_n<KP>(v, w.tw, w.tile, w.lane);
+#pragma unroll
+    for (int c = 0; c < KP; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) o[(size_t)c * H + r * 64 + w.lane] = make_double2(v[c][r].x * 0x1p-9, v[c][r].y * 0x1p-9);
 }
 
 __global__ __launch_bounds__(256) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
@@ -503,17 +590,15 @@ __global__ __launch_bounds__(256) void k_scheme_switch(const uint64_t *glev, cpl
             const cplx *key = ss_f + (((size_t)i * SS_L) * KP + r) * KP * H;
             extprod_row<SS_B, SS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
         }
+        uint64_t rows[KP][16];
 #pragma unroll
-        for (int c = 0; c < KP; c++) {
-            uint64_t row[16];
+        for (int c = 0; c < KP; c++)
 #pragma unroll
-            for (int m = 0; m < 16; m++) row[m] = 0;
-            inv_add(F[c], row, w);
-            store_fourier_scaled(row, o + ((size_t)i * KP + c) * H, w);
-        }
+            for (int m = 0; m < 16; m++) rows[c][m] = 0;
+        inv_add3(F, rows, w);
+        store_fourier_scaled3(rows, o + (size_t)i * KP * H, w);
     }
-#pragma unroll
-    for (int c = 0; c < KP; c++) store_fourier_scaled(in[c], o + ((size_t)2 * KP + c) * H, w);
+    store_fourier_scaled3(in, o + (size_t)2 * KP * H, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -567,17 +652,14 @@ __global__ __launch_bounds__(256) void k_lut_eval(const cplx *ggsw_f, const uint
         zero_f(F);
 #pragma unroll
         for (int r = 0; r < KP; r++) {
-            uint64_t lo[8], hi[8];
+            uint64_t lo[8], hi[8], diff[16];
             poly_to_lds(acc[r], w.pl, lane);
+            rot_sub16(w.pl, acc[r], rot, lane, diff);
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                lo[m] = rot_read(w.pl, lane + 64 * m, rot) - acc[r][m];
-                hi[m] = rot_read(w.pl, lane + 64 * m + 512, rot) - acc[r][m + 8];
-            }
+            for (int m = 0; m < 8; m++) { lo[m] = diff[m]; hi[m] = diff[m + 8]; }
             extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
         }
-#pragma unroll
-        for (int c = 0; c < KP; c++) inv_add(F[c], acc[c], w);
+        inv_add3(F, acc, w);
     }
     const size_t big = BIG;
 #pragma unroll 1
@@ -600,6 +682,11 @@ __global__ __launch_bounds__(256) void k_cmux(uint64_t *ct0, const uint64_t *ct1
     uint64_t *p0 = ct0 + (size_t)w.unit * GL;
     const uint64_t *p1 = ct1 + (size_t)w.unit * GL;
     const cplx *gg = ggsw_f + (size_t)sel[w.unit] * CBS_L * KP * KP * H;
+    uint64_t a0[KP][16];
+#pragma unroll
+    for (int r = 0; r < KP; r++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) a0[r][m] = p0[r * N + w.lane + 64 * m];
     cplx F[KP][8];
     zero_f(F);
 #pragma unroll
@@ -607,20 +694,16 @@ __global__ __launch_bounds__(256) void k_cmux(uint64_t *ct0, const uint64_t *ct1
         uint64_t lo[8], hi[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            lo[m] = p1[r * N + w.lane + 64 * m] - p0[r * N + w.lane + 64 * m];
-            hi[m] = p1[r * N + w.lane + 64 * m + 512] - p0[r * N + w.lane + 64 * m + 512];
+            lo[m] = p1[r * N + w.lane + 64 * m] - a0[r][m];
+            hi[m] = p1[r * N + w.lane + 64 * m + 512] - a0[r][m + 8];
         }
         extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
     }
+    inv_add3(F, a0, w);
 #pragma unroll
-    for (int c = 0; c < KP; c++) {
-        uint64_t row[16];
+    for (int r = 0; r < KP; r++)
 #pragma unroll
-        for (int m = 0; m < 16; m++) row[m] = p0[c * N + w.lane + 64 * m];
-        inv_add(F[c], row, w);
-#pragma unroll
-        for (int m = 0; m < 16; m++) p0[c * N + w.lane + 64 * m] = row[m];
-    }
+        for (int m = 0; m < 16; m++) p0[r * N + w.lane + 64 * m] = a0[r][m];
 }
 
 // ------------------------------------------------------------------------------------------
