@@ -110,7 +110,9 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TRACE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TRACE) != hipSuccess) {
+                            (int)LDS_BYTES_TRACE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the trace kernels"); delete c; return nullptr;
     }
     return c;
@@ -283,7 +285,7 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
-    hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES, c->stream, in, acc, (int)count,
+    hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
                        (int)c->p.n, c->bsk_f, c->tw);
     ev_end(c);
 }

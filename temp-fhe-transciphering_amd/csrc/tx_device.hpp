@@ -76,6 +76,10 @@ __device__ __forceinline__ void dft8(cplx (&v)[8])
 
 // Order LDS traffic of one wave: the hardware executes a wave's DS instructions in order, so a
 // compiler-level fence is all that is needed between a tile write and the dependent tile read.
+// all loads issued before this point stay before it, all users after it: the loads go out back to
+// back and the (automatic, counted) waits land at the first uses
+__device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -95,6 +99,7 @@ __device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = tile[r * XPITCH + lane];
+    issue_fence();
 }
 __device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
 {
@@ -105,6 +110,7 @@ __device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = tile[r * XPITCH + lane];
+    issue_fence();
 }
 
 // forward transform of the 8 complex points held by this lane; tw = [22][64] table in LDS.
@@ -151,6 +157,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
@@ -162,6 +169,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
@@ -175,6 +183,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
@@ -196,6 +205,7 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
@@ -209,6 +219,7 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
@@ -220,6 +231,7 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
         cplx w[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
+        issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll

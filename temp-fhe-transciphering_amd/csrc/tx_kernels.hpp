@@ -75,6 +75,7 @@ __device__ __forceinline__ void load_key8(cplx (&g)[8], const cplx *key, int lan
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) g[r] = key[r * 64 + lane];
+    issue_fence();
 }
 __device__ __forceinline__ void fmac8r(cplx (&acc)[8], const cplx (&d)[8], const cplx (&g)[8])
 {
@@ -347,56 +348,77 @@ __device__ __forceinline__ uint64_t test_vector(int i)
     return (i < N / 2) ? (uint64_t)0 - v : v;
 }
 
-__global__ __launch_bounds__(256) void k_blind_rotate(const uint64_t *lwe, uint64_t *acc_out, int count, int n,
+// LDS of the blind-rotation kernel: twiddles, then per wave: transpose tile + the accumulator
+// (3 x 1024 torus words, natural order).  One workgroup per CU (154 KiB).
+constexpr size_t BR_WAVE_BYTES = SCRATCH_CPLX * sizeof(cplx) + (size_t)GL * sizeof(uint64_t);
+constexpr size_t LDS_BYTES_BR = TW_ROWS * 64 * sizeof(cplx) + WAVES * BR_WAVE_BYTES;
+
+// one-level decomposition with B = 23 on the high dword only (closest multiple of 2^41, balanced digit)
+__device__ __forceinline__ double pbs_digit(uint64_t x)
+{
+    uint32_t s = ((((uint32_t)(x >> 32)) >> 8) + 1) >> 1;       // ((x >> 40) + 1) >> 1
+    s &= 0x7FFFFFu;
+    int32_t d = (int32_t)s - (int32_t)((s > 0x400000u) ? 0x800000u : 0u);
+    return (double)d;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_blind_rotate(const uint64_t *lwe, uint64_t *acc_out, int count, int n,
                                                       const cplx *bsk_f, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    WaveCtx w = wave_setup(tw_g, lds);
+    WaveCtx w = wave_setup(tw_g, lds, BR_WAVE_BYTES);
     if (w.unit >= count) return;
     const uint64_t *ct = lwe + (size_t)w.unit * (n + 1);
     const int lane = w.lane;
-    uint64_t acc[KP][16];
+    uint64_t *accl = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);   // [3][1024] in LDS
     {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
         const int rot = 2 * N - (int)modswitch(ct[n]);      // X^(-b) = X^(2N - b); b in [0, 2N]
 #pragma unroll
         for (int m = 0; m < 16; m++) {
-            acc[0][m] = 0; acc[1][m] = 0;
             int src = lane + 64 * m - rot;                  // in [-2N, N)
             uint64_t neg = 0;
             if (src < 0) { src += N; neg = ~neg; }
             if (src < 0) { src += N; neg = ~neg; }
             uint64_t x = test_vector(src);
-            acc[2][m] = (x ^ neg) - neg;
+            accl[lane + 64 * m] = 0;
+            accl[N + lane + 64 * m] = 0;
+            accl[2 * N + lane + 64 * m] = (x ^ neg) - neg;
         }
     }
-    typedef Decomp<PBS_B, PBS_L> D;
     cplx g[8];
     load_key8(g, bsk_f, lane);                              // key polynomial (step 0, row 0, col 0)
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         // a mask element equal to 0 (skipped at pbs.rs:111) rotates by 0: ct1 = 0 and the step adds 0
-        const int rot = (int)modswitch(ct[i]);
+        const uint32_t rot = modswitch(ct[i]);
+        const uint32_t base = ((uint32_t)lane - rot) & (2 * N - 1);
         // ct1 = acc * X^rot - acc (pbs.rs:125-134), one-level decomposition, digits as f64
         cplx d[KP][8];
+        wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < KP; q++) {
-            poly_to_lds(acc[q], w.pl, lane);
-            uint64_t diff[16];
-            rot_sub16(w.pl, acc[q], rot, lane, diff);
+            const uint64_t *a = accl + q * N;
+            uint64_t own[16], x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) own[m] = a[lane + 64 * m];
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = a[(base + 64 * m) & (N - 1)];
+            issue_fence();
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                D::state_t s0 = D::init(diff[m]), s1 = D::init(diff[m + 8]);
-                d[q][m] = make_double2((double)D::next(s0), (double)D::next(s1));
+                const uint64_t n0 = (uint64_t)0 - (uint64_t)(((base + 64 * m) >> LOGN) & 1);
+                const uint64_t n1 = (uint64_t)0 - (uint64_t)(((base + 64 * (m + 8)) >> LOGN) & 1);
+                d[q][m] = make_double2(pbs_digit(((x[m] ^ n0) - n0) - own[m]),
+                                       pbs_digit(((x[m + 8] ^ n1) - n1) - own[m + 8]));
             }
         }
         fft_fwd_n<KP>(d, w.tw, w.tile, lane);
         const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
         const int inext = (i + 1 < n) ? i + 1 : i;
+        cplx F[KP][8];
+        zero_f(F);
 #pragma unroll
-        for (int c = 0; c < KP; c++) {
-            cplx F[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) F[r] = make_double2(0.0, 0.0);
+        for (int c = 0; c < KP; c++)
 #pragma unroll
             for (int q = 0; q < KP; q++) {
                 cplx gn[8];
@@ -404,18 +426,32 @@ __global__ __launch_bounds__(256) void k_blind_rotate(const uint64_t *lwe, uint6
                                : (c + 1 < KP) ? row + (size_t)(c + 1) * H
                                               : bsk_f + (size_t)inext * KP * KP * H;
                 load_key8(gn, nk, lane);
-                fmac8r(F, d[q], g);
+                fmac8r(F[c], d[q], g);
 #pragma unroll
                 for (int r = 0; r < 8; r++) g[r] = gn[r];
             }
-            inv_add(F, acc[c], w);
+        fft_inv_n<KP>(F, w.tw, w.tile, lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < KP; c++) {
+            uint64_t *a = accl + c * N;
+            uint64_t cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = a[lane + 64 * m];
+            issue_fence();
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                a[lane + 64 * m] = cur[m] + f64_to_torus(F[c][m].x);
+                a[lane + 64 * (m + 8)] = cur[m + 8] + f64_to_torus(F[c][m].y);
+            }
         }
     }
+    wave_lds_fence();
     uint64_t *o = acc_out + (size_t)w.unit * GL;
 #pragma unroll
     for (int q = 0; q < KP; q++)
 #pragma unroll
-        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = acc[q][m];
+        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = accl[q * N + lane + 64 * m];
 }
 
 // ------------------------------------------------------------------------------------------
