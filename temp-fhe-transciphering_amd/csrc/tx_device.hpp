@@ -92,8 +92,12 @@ __device__ __forceinline__ void wave_lds_fence()
 //   xchg_lo: element (lane = 8g+b, reg r)  ->  (lane = 8g+r, reg b)
 __device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
 {
+#ifdef TXD_ABL_NOXCHG
+    return;
+#endif
     const int a = lane >> 3, b = lane & 7;
-    wave_lds_fence();
+    // no fence in front: the stores may sink into the producing butterflies as soon as each value
+    // is final (cplx-typed accesses to the same tile keep their program order by aliasing rules)
 #pragma unroll
     for (int r = 0; r < 8; r++) tile[a * XPITCH + 8 * r + b] = v[r];
     wave_lds_fence();
@@ -103,8 +107,10 @@ __device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
 }
 __device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
 {
+#ifdef TXD_ABL_NOXCHG
+    return;
+#endif
     const int g8 = lane & ~7, b = lane & 7;
-    wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 8; r++) tile[b * XPITCH + g8 + r] = v[r];
     wave_lds_fence();
@@ -153,6 +159,8 @@ __device__ __forceinline__ void fft_inv(cplx (&v)[8], const cplx *tw, cplx *tile
 template <int P>
 __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)
 {
+    // software pipeline over the P polynomials: polynomial p's tile round trip is in flight while
+    // polynomial p+1's butterflies issue; the waits land at the next pass's first use of v[p].
     {
         cplx w[8];
 #pragma unroll
@@ -163,34 +171,32 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
 #pragma unroll
             for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], w[m]);
     }
-#pragma unroll
-    for (int p = 0; p < P; p++) dft8<+1>(v[p]);
     {
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
-        for (int p = 0; p < P; p++)
+        for (int p = 0; p < P; p++) {
+            dft8<+1>(v[p]);
 #pragma unroll
             for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], w[r - 1]);
+            xchg_hi(v[p], tile, lane);
+        }
     }
-#pragma unroll
-    for (int p = 0; p < P; p++) xchg_hi(v[p], tile, lane);
-#pragma unroll
-    for (int p = 0; p < P; p++) dft8<+1>(v[p]);
     {
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
-        for (int p = 0; p < P; p++)
+        for (int p = 0; p < P; p++) {
+            dft8<+1>(v[p]);
 #pragma unroll
             for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], w[r - 1]);
+            xchg_lo(v[p], tile, lane);
+        }
     }
-#pragma unroll
-    for (int p = 0; p < P; p++) xchg_lo(v[p], tile, lane);
 #pragma unroll
     for (int p = 0; p < P; p++) dft8<+1>(v[p]);
 }
@@ -198,35 +204,35 @@ template <int P>
 __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)
 {
 #pragma unroll
-    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
-#pragma unroll
-    for (int p = 0; p < P; p++) xchg_lo(v[p], tile, lane);
+    for (int p = 0; p < P; p++) {
+        dft8<-1>(v[p]);
+        xchg_lo(v[p], tile, lane);
+    }
     {
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
-        for (int p = 0; p < P; p++)
+        for (int p = 0; p < P; p++) {
 #pragma unroll
             for (int r = 1; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r - 1]);
+            dft8<-1>(v[p]);
+            xchg_hi(v[p], tile, lane);
+        }
     }
-#pragma unroll
-    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
-#pragma unroll
-    for (int p = 0; p < P; p++) xchg_hi(v[p], tile, lane);
     {
         cplx w[7];
 #pragma unroll
         for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
-        for (int p = 0; p < P; p++)
+        for (int p = 0; p < P; p++) {
 #pragma unroll
             for (int r = 1; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r - 1]);
+            dft8<-1>(v[p]);
+        }
     }
-#pragma unroll
-    for (int p = 0; p < P; p++) dft8<-1>(v[p]);
     {
         cplx w[8];
 #pragma unroll

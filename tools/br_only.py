@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
 import numpy as np
 import txhip, txclient
+if os.environ.get('TX_LIB'): txhip.LIB_PATH = os.environ['TX_LIB']
 import ctypes as C
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
