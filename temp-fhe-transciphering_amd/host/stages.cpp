@@ -1,0 +1,203 @@
+// stages.cpp -- the ten stage executables of the harness contract (harness/run_submission.py:68-115,
+// submission/Cargo.toml:19-47), one binary dispatched on its own name.  argv: <size>; cwd = the
+// workload root; inputs under datasets/<size>/, everything else under io/<size>/ (SURVEY.md A.11).
+// The server stages are thin wrappers: read files -> C ABI (libtfhe_mi355x.so) -> write files.
+// File format between this repo's own stages (private, like the reference's bincode files):
+// 16-byte header {magic "TXU64\0\0\0", word count} followed by little-endian u64 words.
+#include "txclient.h"
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace {
+
+const char *size_name(int s)
+{   // submission/src/help_fun.rs:3-10
+    static const char *n[] = { "toy", "small", "medium" };
+    if (s < 0 || s > 2) throw std::runtime_error("size must be 0 (toy), 1 (small) or 2 (medium)");
+    return n[s];
+}
+void mkdirs(const std::string &p)
+{
+    std::string cur;
+    for (size_t i = 0; i <= p.size(); i++)
+        if (i == p.size() || p[i] == '/') { cur = p.substr(0, i); if (!cur.empty()) mkdir(cur.c_str(), 0755); }
+}
+void write_words(const std::string &path, const std::vector<uint64_t> &v)
+{
+    mkdirs(path.substr(0, path.find_last_of('/')));
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    uint64_t hdr[2] = { 0x0000003436555854ull /* "TXU64" */, v.size() };
+    if (fwrite(hdr, 8, 2, f) != 2 || fwrite(v.data(), 8, v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short write " + path); }
+    fclose(f);
+}
+std::vector<uint64_t> read_words(const std::string &path)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot read " + path);
+    uint64_t hdr[2];
+    if (fread(hdr, 8, 2, f) != 2 || hdr[0] != 0x0000003436555854ull) { fclose(f); throw std::runtime_error("bad header in " + path); }
+    std::vector<uint64_t> v(hdr[1]);
+    if (fread(v.data(), 8, v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short read " + path); }
+    fclose(f);
+    return v;
+}
+std::string read_text(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot read " + path);
+    std::stringstream ss; ss << f.rdbuf();
+    std::string s = ss.str();
+    while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ')) s.pop_back();
+    return s;
+}
+std::vector<uint8_t> from_hex(const std::string &h)
+{
+    if (h.size() % 2) throw std::runtime_error("odd hex length");
+    std::vector<uint8_t> out(h.size() / 2);
+    for (size_t i = 0; i < out.size(); i++) out[i] = (uint8_t)std::stoul(h.substr(2 * i, 2), nullptr, 16);
+    return out;
+}
+uint64_t env_seed(const char *name) { const char *s = getenv(name); return s ? strtoull(s, nullptr, 10) : 0; }
+
+struct Paths {
+    std::string io, data;
+    explicit Paths(int size) : io(std::string("io/") + size_name(size)), data(std::string("datasets/") + size_name(size)) {}
+};
+
+void check(int rc, const char *what) { if (rc != 0) throw std::runtime_error(std::string(what) + ": " + tx_last_error()); }
+
+// ---------------- client stages ----------------
+int client_key_generation(int size)
+{   // client_key_generation.rs:81-133
+    Paths p(size);
+    tx_params prm; tx_params_aes_tight(&prm);
+    std::vector<uint64_t> lwe(prm.n), glwe((size_t)prm.k * prm.N), bsk(txc_bsk_words(&prm)), ksk(txc_ksk_words(&prm)),
+        au(txc_auto_words(&prm)), ss(txc_ss_words(&prm));
+    if (txc_keygen(&prm, env_seed("TX_SEED"), lwe.data(), glwe.data(), bsk.data(), ksk.data(), au.data(), ss.data()))
+        throw std::runtime_error("key generation failed");
+    write_words(p.io + "/secret_keys/lwe_sk.bin", lwe);
+    write_words(p.io + "/secret_keys/glwe_sk.bin", glwe);
+    write_words(p.io + "/public_keys/bsk.bin", bsk);
+    write_words(p.io + "/public_keys/ksk.bin", ksk);
+    write_words(p.io + "/public_keys/auto_keys.bin", au);
+    write_words(p.io + "/public_keys/ss_key.bin", ss);
+    return 0;
+}
+int client_encode_encrypt(int size)
+{   // client_encode_encrypt.rs:24-66; size 0 is ECB, sizes >= 1 CTR (aes_keygen_and_encrypt.py:45-55)
+    Paths p(size);
+    tx_params prm; tx_params_aes_tight(&prm);
+    std::vector<uint8_t> key = from_hex(read_text(p.data + "/aes_key.hex"));
+    if (key.size() != 16) throw std::runtime_error("aes_key.hex must hold 16 bytes");
+    std::vector<uint64_t> glwe = read_words(p.io + "/secret_keys/glwe_sk.bin");
+    std::vector<uint64_t> luts(size == 0 ? txc_lut_words(&prm) : txc_ctr_lut_words(&prm));
+    uint64_t seed = env_seed("TX_SEED");
+    if (size == 0) txc_make_round_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data());
+    else txc_make_ctr_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data());
+    write_words(p.io + "/ciphertexts_upload/trans_key.bin", luts);
+    return 0;
+}
+int client_decrypt(int size, const char *in_dir, const char *out_name)
+{   // client_decrypt_decode*.rs:18-39
+    Paths p(size);
+    tx_params prm; tx_params_aes_tight(&prm);
+    std::vector<uint64_t> glwe = read_words(p.io + "/secret_keys/glwe_sk.bin");
+    std::vector<uint64_t> ct = read_words(p.io + "/" + in_dir + "/result.bin");
+    const size_t big = (size_t)prm.k * prm.N + 1, cnt = ct.size() / big;
+    std::vector<uint8_t> bits(cnt);
+    txc_decrypt_bits(&prm, glwe.data(), ct.data(), cnt, bits.data());
+    std::vector<uint64_t> w(bits.begin(), bits.end());
+    write_words(p.io + "/intermediate/" + out_name, w);
+    return 0;
+}
+int client_postprocess(int size, const char *in_name, const char *out_name)
+{   // client_postprocess*.rs:18-37: every 16 bits -> u16, first bit = MSB, one decimal per line
+    Paths p(size);
+    std::vector<uint64_t> w = read_words(p.io + "/intermediate/" + in_name);
+    std::vector<uint8_t> bits(w.begin(), w.end());
+    std::vector<uint16_t> v(bits.size() / 16);
+    if (txc_bits_to_u16(bits.data(), bits.size(), v.data())) throw std::runtime_error("bit count is not a multiple of 16");
+    std::ofstream f(p.io + "/" + out_name);
+    for (uint16_t x : v) f << x << "\n";
+    return 0;
+}
+
+// ---------------- server stages ----------------
+tx_ctx *server_context(const Paths &p, const tx_params &prm)
+{   // SRV_AES:620-687
+    int dev = getenv("TX_DEVICE") ? atoi(getenv("TX_DEVICE")) : 0;
+    tx_ctx *c = tx_create(&prm, dev);
+    if (!c) throw std::runtime_error(std::string("tx_create: ") + tx_last_error());
+    std::vector<uint64_t> bsk = read_words(p.io + "/public_keys/bsk.bin"), ksk = read_words(p.io + "/public_keys/ksk.bin"),
+        au = read_words(p.io + "/public_keys/auto_keys.bin"), ss = read_words(p.io + "/public_keys/ss_key.bin");
+    check(tx_load_eval_keys(c, bsk.data(), ksk.data(), au.data(), ss.data()), "tx_load_eval_keys");
+    return c;
+}
+int server_encrypted_aes_decryption(int size)
+{   // SRV_AES:599-707, all blocks of db.hex
+    Paths p(size);
+    tx_params prm; tx_params_aes_tight(&prm);
+    std::vector<uint8_t> ct = from_hex(read_text(p.data + "/db.hex"));
+    if (ct.empty() || ct.size() % 16) throw std::runtime_error("db.hex must hold whole 16-byte blocks");
+    tx_ctx *c = server_context(p, prm);
+    std::vector<uint64_t> luts = read_words(p.io + "/ciphertexts_upload/trans_key.bin");
+    std::vector<uint8_t> iv;
+    if (size == 0) check(tx_load_round_luts(c, luts.data(), luts.size()), "tx_load_round_luts");
+    else { check(tx_load_ctr_luts(c, luts.data(), luts.size()), "tx_load_ctr_luts"); iv = from_hex(read_text(p.data + "/aes_iv.hex")); }
+    const size_t nb = ct.size() / 16, big = (size_t)prm.k * prm.N + 1;
+    std::vector<uint64_t> out(nb * 128 * big);
+    check(tx_transcipher(c, ct.data(), nb, size == 0 ? nullptr : iv.data(), out.data(), 0), "tx_transcipher");
+    tx_destroy(c);
+    write_words(p.io + "/ciphertext_aes_download/result.bin", out);
+    return 0;
+}
+int server_encrypted_compute(int size)
+{   // SRV_CMP:99-359 (mini-workload 0: max)
+    Paths p(size);
+    tx_params prm; tx_params_aes_tight(&prm);
+    std::vector<uint64_t> in = read_words(p.io + "/ciphertext_aes_download/result.bin");
+    const size_t big = (size_t)prm.k * prm.N + 1, nvals = in.size() / big / 16;
+    if (nvals == 0 || in.size() != nvals * 16 * big) throw std::runtime_error("lwe_ciphertext_list length is not a multiple of 16");
+    tx_ctx *c = server_context(p, prm);
+    std::vector<uint64_t> out(16 * big);
+    check(tx_max_u16(c, in.data(), nvals, out.data()), "tx_max_u16");
+    tx_destroy(c);
+    write_words(p.io + "/ciphertexts_download/result.bin", out);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::string name = argv[0];
+    name = name.substr(name.find_last_of('/') + 1);
+    if (argc < 2) { fprintf(stderr, "Usage: %s <size>\n", argv[0]); return 1; }       // SRV_AES:601-604
+    try {
+        const int size = std::stoi(argv[1]);
+        size_name(size);
+        if (name == "client_preprocess" || name == "server_preprocess_dataset") return 0;   // stubs in the reference too
+        if (name == "client_key_generation") return client_key_generation(size);
+        if (name == "client_encode_encrypt") return client_encode_encrypt(size);
+        if (name == "server_encrypted_aes_decryption") return server_encrypted_aes_decryption(size);
+        if (name == "server_encrypted_compute") return server_encrypted_compute(size);
+        if (name == "client_decrypt_decode_aes_decryption") return client_decrypt(size, "ciphertext_aes_download", "decoded_result_aes.txt");
+        if (name == "client_postprocess_aes_decryption") return client_postprocess(size, "decoded_result_aes.txt", "result_aes.txt");
+        if (name == "client_decrypt_decode") return client_decrypt(size, "ciphertexts_download", "decoded_result.txt");
+        if (name == "client_postprocess") return client_postprocess(size, "decoded_result.txt", "result.txt");
+        fprintf(stderr, "%s: unknown stage name\n", name.c_str());
+        return 1;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s: %s\n", name.c_str(), e.what());
+        return 1;
+    }
+}

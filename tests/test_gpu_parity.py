@@ -262,3 +262,23 @@ def test_client_library_keys_end_to_end(rig256):
     out = eng.transcipher(bytes.fromhex(fx["db_hex"]))
     assert txclient.bits_to_u16(ck.decrypt_bits(out)).tolist() == fx["db"]
     eng.close()
+
+
+@pytest.mark.parametrize("size", [0, 1])
+def test_stage_executables_end_to_end(size, tmp_path):
+    """the harness contract: ten stage executables over datasets/ and io/, exact-equality verify
+    (toy = ECB 1 block, small = CTR 8 blocks) incl. the max mini-workload"""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(HERE)
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_submission.py")
+    r = subprocess.run([_sys.executable, rs, str(size), "--root", str(tmp_path), "--seed", "123", "--fhe_seed", "99"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "AES decryption: PASS; max: PASS" in r.stdout
+    name = ["toy", "small"][size]
+    for d in ("public_keys", "ciphertexts_upload", "ciphertext_aes_download", "ciphertexts_download"):
+        assert os.path.isdir(tmp_path / "io" / name / d)
+    import json as _json
+    res = _json.load(open(tmp_path / "measurements" / name / "results.json"))
+    assert set(res) == {"total_latency_s", "per_stage", "bandwidth"}
