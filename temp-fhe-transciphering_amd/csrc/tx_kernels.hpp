@@ -534,7 +534,7 @@ __device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *au
     }
 }
 
-__global__ __launch_bounds__(256) void k_extract_trace(const uint64_t *acc, uint64_t *glev, int count,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_extract_trace(const uint64_t *acc, uint64_t *glev, int count,
                                                        const cplx *auto_f, size_t split_stride, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_extract_trace(const uint64_t *acc, uint
 }
 
 // trace_assign alone on `count` GLWEs in place (unit parity for a7)
-__global__ __launch_bounds__(256) void k_trace(uint64_t *glwe, int count, const cplx *auto_f, size_t split_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_trace(uint64_t *glwe, int count, const cplx *auto_f, size_t split_stride,
                                                const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -607,7 +607,7 @@ __device__ __forceinline__ void store_fourier_scaled3(const uint64_t (&p)[KP][16
         for (int r = 0; r < 8; r++) o[(size_t)c * H + r * 64 + w.lane] = make_double2(v[c][r].x * 0x1p-9, v[c][r].y * 0x1p-9);
 }
 
-__global__ __launch_bounds__(256) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
                                                        const cplx *ss_f, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -670,7 +670,7 @@ __device__ __forceinline__ void sample_extract_store(const uint64_t (&p0)[16], c
     if (w.lane == 0) o[2 * N] = w.pl[nth];
 }
 
-__global__ __launch_bounds__(256) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
                                                   size_t byte_stride, uint64_t *out, int nbytes, int nlut,
                                                   const cplx *tw_g)
 {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void k_lut_eval(const cplx *ggsw_f, const uint
 // cmux (SRV_CMP:81-95 via tfhe cmux_assign): ct0 += g (x) (ct1 - ct0), batched: unit u uses
 // selector sel[u] (index into ggsw_f), GLWEs ct0[u], ct1[u] (ct1 is not modified).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
                                               int units, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
