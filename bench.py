@@ -17,6 +17,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+
+# HBM-side traffic of ONE k_blind_rotate launch over 8192 units (medium on one GPU), from the separate
+# rocprofv3 --pmc passes kept in profiles/r1_pmc_{fetch,write}_size_br_trace.csv:
+# FETCH_SIZE 1 795 972 KiB x 2 (gfx950 counts half of a 16 B/lane streaming read, MI355X_MICROARCH.md HBM)
+# + WRITE_SIZE 196 608 KiB.  The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident
+# batch of waves, mostly from the Infinity Cache.
+BR_TRAFFIC_BYTES_8192 = (1795972 * 2 + 196608) * 1024
+BR_F64_FLOP_PER_UNIT_STEP = 64 * (1080 + 336 + 2 * 648)      # per wave and CMux step: adds, muls, fmas (ISA count)
 
 
 def algorithmic_bytes_per_block(M):
@@ -168,12 +177,17 @@ def main():
                                    f"full 10 rounds, keys resident, result LWEs left in HBM",
                        "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (BR_TRAFFIC_BYTES_8192 if (m_local * 128 == 8192 and args.n == 768) else None),
                          "avg_launch_ms": br_avg_ms, "launches": br_launches[0],
                          "algorithmic_bytes_per_launch": br_launch_bytes(m_local, args.n),
                          "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,
                          "path_frac": value / world * algorithmic_bytes_per_block(m_local) / 1e9 / HBM_PEAK_GBS,
-                         "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction"},
+                         "fp64_valu": {"achieved_TFLOPs": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12,
+                                       "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                                       "frac": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
+                                 "fp64_valu is the informative bound"},
             "kernel_ms_last_step": {k: round(v, 3) for k, v in last_timing.items() if k.startswith("ms_")},
             "setup_s": {"client_keygen": round(t_keygen, 2), "key_upload_and_transform": round(t_load, 3)},
         }
