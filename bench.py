@@ -73,6 +73,7 @@ def main():
                     help="strong: --blocks in total (the medium instance); weak: --blocks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,12 +90,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; a rehearsal with more ranks than GPUs (gloo only) wraps around
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ---- synthetic medium instance: uniform u16 values, big-endian, AES-128 under the harness key
     n_blocks = args.blocks * (world if args.scaling == "weak" else 1)
@@ -114,7 +120,7 @@ def main():
     keys = txclient.ClientKeys(p, seed=args.seed)
     luts = keys.round_luts(aes_key, seed=args.seed + 1) if args.mode == "ecb" else keys.ctr_luts(aes_key, seed=args.seed + 1)
     t_keygen = time.time() - t0
-    eng = txhip.Engine(p, device=local_rank)
+    eng = txhip.Engine(p, device=dev_index)
     t0 = time.time()
     eng.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
     (eng.load_round_luts if args.mode == "ecb" else eng.load_ctr_luts)(luts)

@@ -100,16 +100,12 @@ __device__ __forceinline__ void fmac8r(cplx (&acc)[8], const cplx (&d)[8], const
 // transformed together, then accumulated against the key: F[c] += D[i] * key[lev(i)][c], for fixed c
 // in increasing i (the oracle's order: row outer, level finest-first inner).  Key loads are
 // software-pipelined one polynomial ahead.  lev0 = level index (0 = level 1) of the group's first digit.
-template <int B, int L, int P, int NCOL, typename ST>
-__device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], ST (&shi)[8], int lev0,
-                                              const cplx *key, size_t lev_stride, size_t col_stride, const WaveCtx &w)
+// transform P digit polynomials (already f64) and accumulate them against key polynomials
+// key[(lev0 - i) * lev_stride + c * col_stride], i = 0..P-1
+template <int P, int NCOL>
+__device__ __forceinline__ void mac_group(cplx (&F)[NCOL][8], cplx (&d)[P][8], int lev0, const cplx *key,
+                                          size_t lev_stride, size_t col_stride, const WaveCtx &w)
 {
-    typedef Decomp<B, L> D;
-    cplx d[P][8];
-#pragma unroll
-    for (int i = 0; i < P; i++)
-#pragma unroll
-        for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
     cplx g[8];
     load_key8(g, key + (size_t)lev0 * lev_stride, w.lane);
     fft_fwd_n<P>(d, w.tw, w.tile, w.lane);
@@ -127,6 +123,18 @@ __device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], 
                 for (int r = 0; r < 8; r++) g[r] = gn[r];
             }
         }
+}
+template <int B, int L, int P, int NCOL, typename ST>
+__device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], ST (&shi)[8], int lev0,
+                                              const cplx *key, size_t lev_stride, size_t col_stride, const WaveCtx &w)
+{
+    typedef Decomp<B, L> D;
+    cplx d[P][8];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
+    mac_group<P, NCOL>(F, d, lev0, key, lev_stride, col_stride, w);
 }
 
 // One row of an external product: decompose the 16 coefficients of this lane (lo[m] = coeff
@@ -496,6 +504,24 @@ __device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *au
         const uint32_t t = (N >> idx) + 1;
         automorph_to_lds(g[0], park, t, w.lane);
         automorph_to_lds(g[1], park + N, t, w.lane);
+        // decompose the permuted mask once; park the three signed 13-bit digits of every coefficient
+        // packed in 16-bit fields (finest level in bits 0-15) for the two passes over the split key
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint64_t *pw = park + q * N;
+            uint64_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = pw[w.lane + 64 * m];
+            issue_fence();
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                D::state_t st = D::init(x[m]);
+                uint64_t pk = 0;
+#pragma unroll
+                for (int i = 0; i < AUTO_L; i++) pk |= (uint64_t)(uint16_t)(int16_t)D::next(st) << (16 * i);
+                pw[w.lane + 64 * m] = pk;
+            }
+        }
         {   // body: g[2] += g[2](X^t)   (keyswitch output starts as (0, 0, permuted body))
             automorph_to_lds(g[2], w.pl, t, w.lane);
             uint64_t pb[16];
@@ -512,14 +538,18 @@ __device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *au
 #pragma unroll 1
             for (int q = 0; q < 2; q++) {
                 const uint64_t *pw = park + q * N;
-                uint64_t x[16];
+                uint64_t pk[16];
 #pragma unroll
-                for (int m = 0; m < 16; m++) x[m] = pw[w.lane + 64 * m];
-                D::state_t slo[8], shi[8];
+                for (int m = 0; m < 16; m++) pk[m] = pw[w.lane + 64 * m];
+                issue_fence();
+                cplx d[AUTO_L][8];
 #pragma unroll
-                for (int m = 0; m < 8; m++) { slo[m] = D::init(x[m]); shi[m] = D::init(x[m + 8]); }
+                for (int i = 0; i < AUTO_L; i++)
+#pragma unroll
+                    for (int m = 0; m < 8; m++)
+                        d[i][m] = make_double2((double)(int16_t)(pk[m] >> (16 * i)), (double)(int16_t)(pk[m + 8] >> (16 * i)));
                 const cplx *key = auto_f + (size_t)s * split_stride + (((size_t)idx * 2 + q) * AUTO_L) * KP * H;
-                extprod_group<AUTO_B, AUTO_L, AUTO_L, KP>(F, slo, shi, AUTO_L - 1, key, (size_t)KP * H, H, w);
+                mac_group<AUTO_L, KP>(F, d, AUTO_L - 1, key, (size_t)KP * H, H, w);
             }
             fft_inv_n<KP>(F, w.tw, w.tile, w.lane);
             const int sh = s ? AUTO_SPLIT : 0;
