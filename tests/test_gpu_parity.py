@@ -282,3 +282,17 @@ def test_stage_executables_end_to_end(size, tmp_path):
     import json as _json
     res = _json.load(open(tmp_path / "measurements" / name / "results.json"))
     assert set(res) == {"total_latency_s", "per_stage", "bandwidth"}
+
+
+def test_chunked_batches_match_unchunked(rig256):
+    """more blocks than one workspace chunk (128): results equal block-wise runs (CTR and ECB)"""
+    r = rig256
+    rng = np.random.default_rng(77)
+    ct = rng.integers(0, 256, 16 * 130, dtype=np.uint8).tobytes()
+    out = r.eng.transcipher(ct)
+    assert out.shape[0] == 130 * 128
+    assert np.array_equal(out[128 * 128:], r.eng.transcipher(ct[16 * 128:]))          # second chunk = blocks 128, 129
+    assert np.array_equal(out[:128], r.eng.transcipher(ct[:16]))
+    octr = r.eng.transcipher(ct, iv=AES_IV)
+    import txdist
+    assert np.array_equal(octr[129 * 128:], r.eng.transcipher(ct[16 * 129:], iv=txdist.iv_add(AES_IV, 129)))
