@@ -645,20 +645,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (w.unit >= units) return;
     const uint64_t *gp = glev + (size_t)w.unit * GL;
     cplx *o = ggsw_f + (size_t)w.unit * KP * KP * H;
-    uint64_t in[KP][16];
-#pragma unroll
-    for (int q = 0; q < KP; q++)
-#pragma unroll
-        for (int m = 0; m < 16; m++) in[q][m] = gp[q * N + w.lane + 64 * m];
+    // the GLev element is re-read from global memory (L2) where needed instead of being held in
+    // 96 registers for the whole kernel
 #pragma unroll 1
     for (int i = 0; i < 2; i++) {
         cplx F[KP][8];
         zero_f(F);
-#pragma unroll
+#pragma unroll 1
         for (int r = 0; r < KP; r++) {
             uint64_t lo[8], hi[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { lo[m] = in[r][m]; hi[m] = in[r][m + 8]; }
+            for (int m = 0; m < 8; m++) { lo[m] = gp[r * N + w.lane + 64 * m]; hi[m] = gp[r * N + w.lane + 64 * m + 512]; }
             const cplx *key = ss_f + (((size_t)i * SS_L) * KP + r) * KP * H;
             extprod_row<SS_B, SS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
         }
@@ -670,7 +667,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         inv_add3(F, rows, w);
         store_fourier_scaled3(rows, o + (size_t)i * KP * H, w);
     }
-    store_fourier_scaled3(in, o + (size_t)2 * KP * H, w);
+    {
+        uint64_t in[KP][16];
+#pragma unroll
+        for (int q = 0; q < KP; q++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) in[q][m] = gp[q * N + w.lane + 64 * m];
+        store_fourier_scaled3(in, o + (size_t)2 * KP * H, w);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
