@@ -78,6 +78,8 @@ def main():
 
     import numpy as np
     import torch
+    import __graft_entry__
+    __graft_entry__.build()                      # no-op when the in-tree libraries are up to date (file-locked)
     import txhip
     import txclient
     import txdist

@@ -10,6 +10,10 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the in-tree shared libraries are build artefacts (git-ignored): (re)build them when they are
+    # missing or older than their sources; hipcc cross-compiles without a GPU
+    import __graft_entry__
+    __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
