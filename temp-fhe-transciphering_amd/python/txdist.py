@@ -41,3 +41,27 @@ def transcipher_sharded(local_fn, ct, iv, rank, world, dist=None, empty_like=Non
         return torch.cat(rows, dim=0)
     dist.gather(local, gather_list=None, dst=0)
     return None
+
+
+def max_sharded(local_max_fn, local_lwe_bits, n_local_values, rank, world, dist=None):
+    """post-transcipher max across ranks: every rank reduces its own values to one
+    16-bit maximum (local_max_fn(tensor[n*16, words]) -> tensor[16, words]), the G partial maxima are
+    gathered to rank 0 (16 LWEs = 262 KB each, one exchange step), and rank 0 finishes with one more
+    tournament over the G survivors.  Ranks without values contribute nothing."""
+    import torch
+    part = local_max_fn(local_lwe_bits[: n_local_values * 16]) if n_local_values > 0 else None
+    if world == 1 or dist is None:
+        return part
+    words = local_lwe_bits.shape[1]
+    buf = part if part is not None else torch.zeros((16, words), dtype=local_lwe_bits.dtype, device=local_lwe_bits.device)
+    have = torch.tensor([1 if part is not None else 0], dtype=torch.int64, device=local_lwe_bits.device)
+    if rank == 0:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        flags = [torch.empty_like(have) for _ in range(world)]
+        dist.gather(buf, gather_list=parts, dst=0)
+        dist.gather(have, gather_list=flags, dst=0)
+        survivors = [p for p, f in zip(parts, flags) if int(f.item()) == 1]
+        return local_max_fn(torch.cat(survivors, dim=0))
+    dist.gather(buf, gather_list=None, dst=0)
+    dist.gather(have, gather_list=None, dst=0)
+    return None

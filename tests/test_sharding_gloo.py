@@ -57,11 +57,23 @@ def _worker(rank, world, port, mode, q):
         return out
 
     res = txdist.transcipher_sharded(local_fn, ct, ivv, rank, world, dist)
+    # the max mini-workload over the sharded result: local tournament, gather of the partial maxima, final tournament
+    _, n_local = txdist.shard(nb, world, rank)
+    mine = local_fn(ct[16 * txdist.shard(nb, world, rank)[0]:16 * (txdist.shard(nb, world, rank)[0] + n_local)],
+                    txdist.iv_add(ivv, txdist.shard(nb, world, rank)[0]) if ivv is not None else None, n_local, n_local)
+
+    def local_max(t):
+        return torch.from_numpy(ctx.max_u16(np.ascontiguousarray(t.numpy().view(np.uint64)), tournament=True).view(np.int64))
+
+    mx = txdist.max_sharded(local_max, mine, n_local * 8, rank, world, dist)
     if rank == 0:
         bits = O.lwe_decrypt_bits(keys.glwe_sk, res.numpy().view(np.uint64))
-        q.put(O.bits_msb_to_bytes(bits) == pt)
+        ok = O.bits_msb_to_bytes(bits) == pt
+        mbits = O.lwe_decrypt_bits(keys.glwe_sk, mx.numpy().view(np.uint64))
+        ok = ok and int("".join(str(int(b)) for b in mbits), 2) == max(fx["db"][: 8 * nb])
+        q.put(ok)
     else:
-        assert res is None
+        assert res is None and mx is None
     dist.barrier()
     dist.destroy_process_group()
 
