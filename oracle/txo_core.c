@@ -128,8 +128,16 @@ static void poly_mul_small_acc(uint32_t N, const uint64_t *a, const int64_t *s, 
 }
 
 /* ---------------- tfhe-rs primitives restated ---------------- */
-/* SignedDecomposer::{closest_representable, decompose}; digits[0] = level `level` (finest) */
-void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digits)
+/* SignedDecomposer::{closest_representable, decompose}; digits[0] = level `level` (finest).
+ * ONE deliberate deviation from tfhe-rs 0.5.4: at the top level (level 1) tfhe-rs resolves the tie
+ * res == B/2 always to +B/2 (no higher bits are left to balance it), which gives the top digit a mean of
+ * +B/8 for B = 4 (tie probability 1/4).  Multiplied by the structured noise e * s_i(X) of the scheme-
+ * switched GGSW rows this bias adds a position-dependent term that dominates the LUT output noise
+ * (measured: external product 2^55.6 -> 2^54.7, LUT output 2^57.4 -> 2^56.1, bootstrap margin 5.9 -> 9.6
+ * sigma; one wrong bit per ~10^6 bootstraps with the tfhe rule).  Here the tie goes to +B/2 on even and
+ * -B/2 on odd coefficient indices (`odd`): the same value mod 2^64, zero mean.  Compile with
+ * -DTXO_TFHE_TOP_DIGIT to get tfhe-rs' rule back. */
+void txo_decompose_idx(uint64_t x, uint32_t base_log, uint32_t level, uint32_t odd, int64_t *digits)
 {
     uint32_t nonrep = 64 - base_log * level;
     uint64_t r = x;
@@ -141,14 +149,22 @@ void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digit
     }
     uint64_t state = nonrep ? (r >> nonrep) : r;
     uint64_t mask = ((uint64_t)1 << base_log) - 1;
+#ifdef TXO_TFHE_TOP_DIGIT
+    odd = 0;
+#endif
+    uint64_t tie = (uint64_t)(odd & 1) << (base_log - 1);
     for (uint32_t i = 0; i < level; i++) {
         uint64_t res = state & mask;
         state >>= base_log;
-        uint64_t carry = ((res - 1) | state) & res;
+        uint64_t carry = ((res - 1) | state | (i + 1 == level ? tie : 0)) & res;
         carry >>= (base_log - 1);
         state += carry;
         digits[i] = (int64_t)(res - (carry << base_log));
     }
+}
+void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digits)
+{   /* even-index form (= tfhe-rs' rule exactly) */
+    txo_decompose_idx(x, base_log, level, 0, digits);
 }
 /* fast_pbs_modulus_switch(x, N, offset 0, lut_count_log) */
 uint32_t txo_modswitch(uint64_t x, uint32_t log2N, uint32_t log_lut_count)
@@ -385,7 +401,7 @@ void txo_extprod_add(const txo_params *p, uint64_t *out, const double *gF, const
     memset(facc, 0, sizeof(double) * (size_t)K * N);
     for (uint32_t r = 0; r < K; r++)
         for (uint32_t j = 0; j < N; j++) {
-            txo_decompose(in[(size_t)r * N + j], B, l, d);
+            txo_decompose_idx(in[(size_t)r * N + j], B, l, j & 1, d);
             for (uint32_t i = 0; i < l; i++) dig[((size_t)i * K + r) * N + j] = d[i];
         }
     /* summation order of the f64 accumulators: row outer, level (finest first) inner, as the HIP
@@ -420,7 +436,7 @@ static void lwe_keyswitch_one(const txo_ctx *c, const uint64_t *in, uint64_t *ou
         g[0] = a[0];
         for (uint32_t j = 1; j < Nc; j++) g[j] = (uint64_t)0 - a[Nc - j];
         for (uint32_t j = 0; j < Nc; j++) {
-            txo_decompose(g[j], p->ks_base_log, l, d);
+            txo_decompose_idx(g[j], p->ks_base_log, l, j & 1, d);
             for (uint32_t i = 0; i < l; i++) dig[(size_t)i * Nc + j] = d[i];
         }
         for (uint32_t i = 0; i < l; i++) {
@@ -506,7 +522,7 @@ static void auto_keyswitch_add(const txo_ctx *c, uint32_t idx /* i-1 */, uint64_
     for (uint32_t q = 0; q < K; q++) txo_poly_auto(N, ct + (size_t)q * N, t, pw + (size_t)q * N);
     for (uint32_t q = 0; q < k; q++) {
         for (uint32_t j = 0; j < N; j++) {
-            txo_decompose(pw[(size_t)q * N + j], p->auto_base_log, l, d);
+            txo_decompose_idx(pw[(size_t)q * N + j], p->auto_base_log, l, j & 1, d);
             for (uint32_t i = 0; i < l; i++) dig[(size_t)i * N + j] = d[i];
         }
         for (uint32_t i = 0; i < l; i++) txo_fft_forward_int(N, dig + (size_t)i * N, D + (size_t)i * N);

@@ -161,6 +161,9 @@ void txo_fft_forward_torus_scaled(uint32_t N, const uint64_t *in, double *out);
 void txo_fft_inverse_add(uint32_t N, const double *in, uint64_t *acc_out);
 /* signed decomposition of one value, finest level first (tfhe SignedDecomposer::decompose) */
 void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digits);
+/* same for the coefficient of index parity `odd`: the top-level tie B/2 goes to -B/2 on odd indices
+ * (the one deviation from tfhe-rs, see txo_core.c) */
+void txo_decompose_idx(uint64_t x, uint32_t base_log, uint32_t level, uint32_t odd, int64_t *digits);
 uint32_t txo_modswitch(uint64_t x, uint32_t log2N, uint32_t log_lut_count);
 /* cleartext AES-128 (aes_manager.rs:131-433) */
 void txo_aes128_expand(const uint8_t key[16], uint8_t rk[11][16]);

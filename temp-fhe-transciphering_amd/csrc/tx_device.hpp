@@ -277,17 +277,22 @@ struct Decomp {
         uint64_t s = ((x >> (NONREP - 1)) + 1) >> 1;
         return (state_t)(s & ((((uint64_t)1) << BL) - 1));
     }
-    // next digit (level L first, then L-1, ...)
-    __device__ static __forceinline__ int32_t next(state_t &st)
+    // next digit (level L first, then L-1, ...).  `tie` is 0 except when the TOP level (level 1)
+    // is extracted on an odd coefficient index, where it is 1 << (B-1): the tie res == B/2, which
+    // tfhe-rs always resolves to +B/2 at the top level, then goes to -B/2 (same value mod 2^64).
+    // This removes the +B/8 mean of the top digit that otherwise dominates the LUT output noise
+    // (oracle/txo_core.c, txo_decompose_idx).
+    __device__ static __forceinline__ int32_t next(state_t &st, state_t tie = 0)
     {
         const state_t mask = (((state_t)1) << B) - 1;
         state_t res = st & mask;
         st >>= B;
-        state_t carry = ((res - 1) | st) & res;
+        state_t carry = ((res - 1) | st | tie) & res;
         carry >>= (B - 1);
         st += carry;
         return (int32_t)res - (int32_t)(carry << B);
     }
+    __device__ static __forceinline__ state_t tie_mask(int lane) { return (state_t)(lane & 1) << (B - 1); }
 };
 
 // ---- coefficient-domain helpers on the 16-words-per-lane register layout ----

@@ -131,9 +131,11 @@ __device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], 
     typedef Decomp<B, L> D;
     cplx d[P][8];
 #pragma unroll
-    for (int i = 0; i < P; i++)
+    for (int i = 0; i < P; i++) {
+        const ST tie = (lev0 - i == 0) ? D::tie_mask(w.lane) : (ST)0;      // top level: balanced tie
 #pragma unroll
-        for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m]), (double)D::next(shi[m]));
+        for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m], tie), (double)D::next(shi[m], tie));
+    }
     mac_group<P, NCOL>(F, d, lev0, key, lev_stride, col_stride, w);
 }
 
@@ -308,10 +310,11 @@ __global__ __launch_bounds__(256) void k_lwe_keyswitch(const uint64_t *in, uint6
 #pragma unroll 1
         for (int i = 0; i < KS_L; i++) {
             const int lev = KS_L - 1 - i;
+            const D::state_t tie = (lev == 0) ? D::tie_mask(lane) : 0;       // top level: balanced tie
             // complex point lane      = (g[lane],      g[lane + 128])  -> regs r = 0, 2
             // complex point lane + 64 = (g[lane + 64], g[lane + 192])  -> regs r = 1, 3
-            double d0 = (double)D::next(st[0]), d1 = (double)D::next(st[1]);
-            double d2 = (double)D::next(st[2]), d3 = (double)D::next(st[3]);
+            double d0 = (double)D::next(st[0], tie), d1 = (double)D::next(st[1], tie);
+            double d2 = (double)D::next(st[2], tie), d3 = (double)D::next(st[3], tie);
             cplx x0 = make_double2(d0, d2), x1 = make_double2(d1, d3);
             fft128_fwd(x0, x1, twist, wt, lane);
             const cplx *key = ksk_f + ((size_t)(q * KS_L + lev) * Kout) * 128;
@@ -368,11 +371,12 @@ constexpr size_t BR_WAVE_BYTES = SCRATCH_CPLX * sizeof(cplx) + (size_t)GL * size
 constexpr size_t LDS_BYTES_BR = TW_ROWS * 64 * sizeof(cplx) + WAVES * BR_WAVE_BYTES;
 
 // one-level decomposition with B = 23 on the high dword only (closest multiple of 2^41, balanced digit)
-__device__ __forceinline__ double pbs_digit(uint64_t x)
+// `thr` = 0x400000 on even, 0x3FFFFF on odd coefficient indices (balanced top-level tie)
+__device__ __forceinline__ double pbs_digit(uint64_t x, uint32_t thr)
 {
     uint32_t s = ((((uint32_t)(x >> 32)) >> 8) + 1) >> 1;       // ((x >> 40) + 1) >> 1
     s &= 0x7FFFFFu;
-    int32_t d = (int32_t)s - (int32_t)((s > 0x400000u) ? 0x800000u : 0u);
+    int32_t d = (int32_t)s - (int32_t)((s > thr) ? 0x800000u : 0u);
     return (double)d;
 }
 
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             accl[2 * N + lane + 64 * m] = (x ^ neg) - neg;
         }
     }
+    const uint32_t thr = 0x400000u - (uint32_t)(lane & 1);
     cplx g[8];
     load_key8(g, bsk_f, lane);                              // key polynomial (step 0, row 0, col 0)
 #pragma unroll 1
@@ -422,8 +427,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int m = 0; m < 8; m++) {
                 const uint64_t n0 = (uint64_t)0 - (uint64_t)(((base + 64 * m) >> LOGN) & 1);
                 const uint64_t n1 = (uint64_t)0 - (uint64_t)(((base + 64 * (m + 8)) >> LOGN) & 1);
-                d[q][m] = make_double2(pbs_digit(((x[m] ^ n0) - n0) - own[m]),
-                                       pbs_digit(((x[m + 8] ^ n1) - n1) - own[m + 8]));
+                d[q][m] = make_double2(pbs_digit(((x[m] ^ n0) - n0) - own[m], thr),
+                                       pbs_digit(((x[m + 8] ^ n1) - n1) - own[m + 8], thr));
             }
         }
         fft_fwd_n<KP>(d, w.tw, w.tile, lane);
@@ -518,7 +523,8 @@ __device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *au
                 D::state_t st = D::init(x[m]);
                 uint64_t pk = 0;
 #pragma unroll
-                for (int i = 0; i < AUTO_L; i++) pk |= (uint64_t)(uint16_t)(int16_t)D::next(st) << (16 * i);
+                for (int i = 0; i < AUTO_L; i++)
+                    pk |= (uint64_t)(uint16_t)(int16_t)D::next(st, (i == AUTO_L - 1) ? D::tie_mask(w.lane) : (D::state_t)0) << (16 * i);
                 pw[w.lane + 64 * m] = pk;
             }
         }

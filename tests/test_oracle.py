@@ -126,16 +126,36 @@ def test_signed_decomposition_recomposes(B, l):
     xs = list(rng.integers(0, 1 << 64, 2000, dtype=np.uint64)) + [0, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, 1 << (63 - B)]
     d = (C.c_int64 * 16)()
     nonrep = 64 - B * l
-    for x in xs:
-        x = int(x)
-        L.txo_decompose(C.c_uint64(x), C.c_uint32(B), C.c_uint32(l), d)
-        digs = [d[i] for i in range(l)]
-        assert all(-(1 << (B - 1)) <= v <= (1 << (B - 1)) for v in digs)
-        # digits[i] is level l - i; recomposition equals the closest representable value
-        rec = sum(v << (64 - B * (l - i)) for i, v in enumerate(digs)) % (1 << 64)
-        closest = (((x >> (nonrep - 1)) + 1) >> 1 << nonrep) % (1 << 64)
-        assert rec == closest
-        assert min((x - closest) % (1 << 64), (closest - x) % (1 << 64)) <= 1 << (nonrep - 1)
+    for odd in (0, 1):
+        for x in xs:
+            x = int(x)
+            L.txo_decompose_idx(C.c_uint64(x), C.c_uint32(B), C.c_uint32(l), C.c_uint32(odd), d)
+            digs = [d[i] for i in range(l)]
+            assert all(-(1 << (B - 1)) <= v <= (1 << (B - 1)) for v in digs)
+            # digits[i] is level l - i; recomposition equals the closest representable value mod 2^64
+            rec = sum(v << (64 - B * (l - i)) for i, v in enumerate(digs)) % (1 << 64)
+            closest = (((x >> (nonrep - 1)) + 1) >> 1 << nonrep) % (1 << 64)
+            assert rec == closest
+            assert min((x - closest) % (1 << 64), (closest - x) % (1 << 64)) <= 1 << (nonrep - 1)
+            if odd == 0:                       # even indices: exactly tfhe-rs' rule
+                L.txo_decompose(C.c_uint64(x), C.c_uint32(B), C.c_uint32(l), d)
+                assert digs == [d[i] for i in range(l)]
+
+
+def test_top_digit_is_balanced_across_coefficient_parity():
+    """the one deviation from tfhe-rs: the top-level tie B/2 alternates sign with the coefficient index,
+    so the top digit has (nearly) zero mean over a polynomial (tfhe-rs: about +0.4 for B = 4)"""
+    L = O.lib()
+    rng = np.random.default_rng(4)
+    d = (C.c_int64 * 16)()
+    tops = {0: [], 1: []}
+    for j, x in enumerate(rng.integers(0, 1 << 64, 20000, dtype=np.uint64)):
+        L.txo_decompose_idx(C.c_uint64(int(x)), 2, 7, j & 1, d)
+        tops[j & 1].append(d[6])
+    # a tie has probability about 1/4 and moves the digit by B = 4: the two parities differ by about 1
+    assert np.mean(tops[0]) > 0.3 and np.mean(tops[1]) < -0.3 and 0.6 < np.mean(tops[0]) - np.mean(tops[1]) < 1.2
+    assert abs(np.mean(tops[0] + tops[1])) < 0.15
+    assert set(tops[0]) == {-1, 0, 1, 2} and set(tops[1]) == {-2, -1, 0, 1}
 
 
 def test_modswitch_is_multiple_of_lut_count_and_rounds():
