@@ -87,6 +87,14 @@ int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks,
  * out: 16 LWE ciphertexts. */
 int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe);
 
+/* Mini-workload 1 of the harness (harness/cleartext_impl.py:65-70; the reference has no server
+ * implementation of it): sum over i < n/2 of (v[i] * v[i + n/2] mod 2^16), mod 2^16, for n_values
+ * (even) 16-bit values given as n_values*16 LWE bits, MSB first.  Bit-sliced: partial products by
+ * CMux with circuit-bootstrapped selectors, carry-save reduction with full adders
+ * (carry = (a^b) ? c : a, sum = (a^b) ? !c : c, one circuit bootstrap of a^b per adder), final
+ * ripple-carry row.  out: 16 LWE ciphertexts, MSB first. */
+int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe);
+
 /* ---- stage-level entry points (one per row of SURVEY.md section 8a), host pointers ---- */
 /* a4 keyswitch_lwe_ciphertext_by_glwe_keyswitch (fourier_glwe_keyswitch.rs:344-379) */
 int tx_stage_lwe_keyswitch(tx_ctx *c, const uint64_t *lwe_big, size_t count, uint64_t *lwe_small);

@@ -401,3 +401,115 @@ void txo_max_u16(const txo_ctx *c, const uint64_t *lwe_bits, size_t n_values, in
     memcpy(out16, cur, sizeof(uint64_t) * v16);
     free(cur);
 }
+
+/* ---------------- inner product mod 2^16, bit-sliced ---------------- */
+typedef struct { int sel, c0, f0, c1, f1, out; } ip_job;
+typedef struct { int *sel0, *sel1; int nsel; ip_job *jobs; int njobs; } ip_level;
+typedef struct { int *v; int n, cap; } ivec;
+static void iv_push(ivec *q, int x) { if (q->n == q->cap) { q->cap = q->cap ? 2 * q->cap : 16; q->v = (int *)realloc(q->v, sizeof(int) * q->cap); } q->v[q->n++] = x; }
+
+typedef struct { ip_level *lv; int nlv, cap; } ip_sched;
+static ip_level *new_level(ip_sched *s, int maxsel, int maxjobs)
+{
+    if (s->nlv == s->cap) { s->cap = s->cap ? 2 * s->cap : 32; s->lv = (ip_level *)realloc(s->lv, sizeof(ip_level) * s->cap); }
+    ip_level *L = &s->lv[s->nlv++];
+    L->sel0 = (int *)malloc(sizeof(int) * (maxsel + 1)); L->sel1 = (int *)malloc(sizeof(int) * (maxsel + 1));
+    L->jobs = (ip_job *)malloc(sizeof(ip_job) * (maxjobs + 2)); L->nsel = 0; L->njobs = 0;
+    return L;
+}
+static void full_adder(ip_level *L, int a, int b, int cc, int k, int *next, int *sum, int *carry)
+{
+    int si = L->nsel; L->sel0[si] = a; L->sel1[si] = b; L->nsel++;
+    *sum = (*next)++;
+    ip_job js = { si, cc, 0, cc, 1, *sum }; L->jobs[L->njobs++] = js;           /* t ? !c : c */
+    *carry = -1;
+    if (k < 15) { *carry = (*next)++; ip_job jc = { si, a, 0, cc, 0, *carry }; L->jobs[L->njobs++] = jc; }   /* t ? c : a */
+}
+
+void txo_inner_product_u16(const txo_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out16)
+{
+    const txo_params *p = &c->p;
+    size_t K = p->k + 1, gl = K * p->N, big = (size_t)p->k * p->N + 1, gsz = (size_t)p->cbs_level * K * gl;
+    int P = (int)(n_values / 2), next = 32 * P;
+    ip_sched S = { 0, 0, 0 };
+    ivec cols[16]; memset(cols, 0, sizeof cols);
+    {   /* partial products */
+        ip_level *L = new_level(&S, 16 * P, 136 * P);
+        for (int pr = 0; pr < P; pr++)
+            for (int j = 0; j < 16; j++) {
+                int si = L->nsel; L->sel0[si] = (pr + P) * 16 + 15 - j; L->sel1[si] = -1; L->nsel++;
+                for (int b = 0; b + j < 16; b++) {
+                    ip_job jb = { si, -1, 0, pr * 16 + 15 - b, 0, next }; L->jobs[L->njobs++] = jb;
+                    iv_push(&cols[b + j], next++);
+                }
+            }
+    }
+    for (;;) {
+        int done = 1, tot = 0;
+        for (int k = 0; k < 16; k++) { if (cols[k].n > 2) done = 0; tot += cols[k].n; }
+        if (done) break;
+        ip_level *L = new_level(&S, tot / 3 + 16, 2 * (tot / 3 + 16));
+        ivec nc[16]; memset(nc, 0, sizeof nc);
+        for (int k = 0; k < 16; k++) {
+            int i = 0;
+            for (; i + 3 <= cols[k].n; i += 3) {
+                int sum, carry;
+                full_adder(L, cols[k].v[i], cols[k].v[i + 1], cols[k].v[i + 2], k, &next, &sum, &carry);
+                iv_push(&nc[k], sum);
+                if (carry >= 0) iv_push(&nc[k + 1], carry);
+            }
+            for (; i < cols[k].n; i++) iv_push(&nc[k], cols[k].v[i]);
+        }
+        for (int k = 0; k < 16; k++) { free(cols[k].v); cols[k] = nc[k]; }
+    }
+    int zero_slot = next++, result[16], carry_in = -1;
+    for (int k = 0; k < 16; k++) {
+        int bits[3], nb = 0;
+        for (int i = 0; i < cols[k].n; i++) bits[nb++] = cols[k].v[i];
+        if (carry_in >= 0) bits[nb++] = carry_in;
+        carry_in = -1;
+        if (nb == 0) { result[k] = zero_slot; continue; }
+        if (nb == 1) { result[k] = bits[0]; continue; }
+        ip_level *L = new_level(&S, 1, 2);
+        if (nb == 2) {
+            L->sel0[0] = bits[0]; L->sel1[0] = -1; L->nsel = 1;
+            result[k] = next++;
+            ip_job js = { 0, bits[1], 0, bits[1], 1, result[k] }; L->jobs[L->njobs++] = js;
+            if (k < 15) { carry_in = next++; ip_job jc = { 0, -1, 0, bits[1], 0, carry_in }; L->jobs[L->njobs++] = jc; }
+        } else {
+            int sum, carry;
+            full_adder(L, bits[0], bits[1], bits[2], k, &next, &sum, &carry);
+            result[k] = sum; carry_in = carry;
+        }
+    }
+    /* evaluate */
+    uint64_t *pool = (uint64_t *)calloc((size_t)next * big, sizeof(uint64_t));
+    memcpy(pool, lwe_bits, sizeof(uint64_t) * n_values * 16 * big);
+    for (int li = 0; li < S.nlv; li++) {
+        ip_level *L = &S.lv[li];
+        uint64_t *t = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)L->nsel * big);
+        for (int i = 0; i < L->nsel; i++)
+            for (size_t w = 0; w < big; w++)
+                t[(size_t)i * big + w] = pool[(size_t)L->sel0[i] * big + w] + (L->sel1[i] >= 0 ? pool[(size_t)L->sel1[i] * big + w] : 0);
+        double *gf = (double *)malloc(sizeof(double) * (size_t)L->nsel * gsz);
+        txo_circuit_bootstrap(c, t, (size_t)L->nsel, gf);
+        #pragma omp parallel for num_threads(txo_get_threads()) schedule(dynamic)
+        for (int i = 0; i < L->njobs; i++) {
+            ip_job jb = L->jobs[i];
+            uint64_t *g0 = (uint64_t *)calloc(gl, sizeof(uint64_t)), *g1 = (uint64_t *)calloc(gl, sizeof(uint64_t));
+            if (jb.c0 >= 0) lwe_to_glwe_const(p, pool + (size_t)jb.c0 * big, g0);
+            if (jb.c1 >= 0) lwe_to_glwe_const(p, pool + (size_t)jb.c1 * big, g1);
+            if (jb.f0) g0[(size_t)p->k * p->N] += (uint64_t)1 << 63;
+            if (jb.f1) g1[(size_t)p->k * p->N] += (uint64_t)1 << 63;
+            cmux(c, g0, g1, gf + (size_t)jb.sel * gsz);
+            txo_sample_extract(p, g0, 0, pool + (size_t)jb.out * big);
+            free(g0); free(g1);
+        }
+        free(t); free(gf);
+    }
+    for (int k = 0; k < 16; k++) memcpy(out16 + (size_t)(15 - k) * big, pool + (size_t)result[k] * big, sizeof(uint64_t) * big);
+    free(pool);
+    for (int k = 0; k < 16; k++) free(cols[k].v);
+    for (int li = 0; li < S.nlv; li++) { free(S.lv[li].sel0); free(S.lv[li].sel1); free(S.lv[li].jobs); }
+    free(S.lv);
+}

@@ -151,6 +151,11 @@ void txo_transcipher_ctr(const txo_ctx *c, const uint64_t *ctr_luts, const uint8
 void txo_max_u16(const txo_ctx *c, const uint64_t *lwe_bits, size_t n_values, int tournament,
                  uint64_t *out16);
 
+/* harness mini-workload 1 (harness/cleartext_impl.py:65-70; no reference server implementation):
+ * sum_{i<n/2} (v[i]*v[i+n/2] mod 2^16) mod 2^16 on n_values*16 LWE bits (MSB first), bit-sliced with
+ * the same gate schedule as the HIP library (tx_inner_product_u16).  out: 16 LWEs, MSB first. */
+void txo_inner_product_u16(const txo_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out16);
+
 /* ---------------- primitives exposed for unit pins ---------------- */
 /* exact negacyclic product mod 2^64 (schoolbook, like glwe_keyswitch.rs:220-303) */
 void txo_poly_mul_exact(uint32_t N, const int64_t *small, const uint64_t *big, uint64_t *out);

@@ -5,6 +5,7 @@
 // tx_kernels.hpp.  There is no CPU fallback: every entry point fails if HIP does.
 #include "../../include/tfhe_mi355x.h"
 #include "tx_kernels.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -575,6 +576,148 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
         cnt = nx;
     }
     HIP_OK(hipMemcpyAsync(out_lwe, pc, v16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+
+// ---- inner product mod 2^16 (harness mini-workload 1), bit-sliced over CMux + circuit bootstrapping ----
+namespace {
+struct Job { int sel; int c0, f0, c1, f1, out; };           // cmux: out = sel ? (c1 ^ f1) : (c0 ^ f0); src -1 = zero
+struct Level { std::vector<std::pair<int, int>> sel; std::vector<Job> jobs; };
+
+// Deterministic schedule shared (by construction, not by code) with the oracle: slots 0..32P-1 are the
+// input bits (value v, bit b -> v*16 + 15 - b); every gate output takes the next slot number.
+struct IpSchedule {
+    std::vector<Level> levels;
+    int result[16];
+    int n_slots, zero_slot;
+};
+IpSchedule ip_schedule(int P)
+{
+    IpSchedule s;
+    int next = 32 * P;
+    auto in = [](int v, int b) { return v * 16 + 15 - b; };
+    std::vector<std::vector<int>> cols(16);
+    {   // partial products: x_b AND y_j = cmux(sel y_j; 0, x_b)
+        Level L;
+        for (int p = 0; p < P; p++)
+            for (int j = 0; j < 16; j++) {
+                const int selidx = (int)L.sel.size();
+                L.sel.push_back({in(p + P, j), -1});
+                for (int b = 0; b + j < 16; b++) {
+                    L.jobs.push_back({selidx, -1, 0, in(p, b), 0, next});
+                    cols[b + j].push_back(next++);
+                }
+            }
+        s.levels.push_back(L);
+    }
+    auto full_adder = [&](Level &L, int a, int b, int c, int k, int &sum, int &carry) {
+        const int selidx = (int)L.sel.size();
+        L.sel.push_back({a, b});                           // t = a ^ b
+        sum = next++;
+        L.jobs.push_back({selidx, c, 0, c, 1, sum});       // t ? !c : c
+        carry = -1;
+        if (k < 15) { carry = next++; L.jobs.push_back({selidx, a, 0, c, 0, carry}); }   // t ? c : a
+    };
+    for (;;) {  // carry-save levels
+        bool done = true;
+        for (int k = 0; k < 16; k++) if (cols[k].size() > 2) done = false;
+        if (done) break;
+        Level L;
+        std::vector<std::vector<int>> nc(16);
+        for (int k = 0; k < 16; k++) {
+            const std::vector<int> &q = cols[k];
+            size_t i = 0;
+            for (; i + 3 <= q.size(); i += 3) {
+                int sum, carry;
+                full_adder(L, q[i], q[i + 1], q[i + 2], k, sum, carry);
+                nc[k].push_back(sum);
+                if (carry >= 0) nc[k + 1].push_back(carry);
+            }
+            for (; i < q.size(); i++) nc[k].push_back(q[i]);
+        }
+        cols = nc;
+        s.levels.push_back(L);
+    }
+    s.zero_slot = next++;
+    int carry_in = -1;
+    for (int k = 0; k < 16; k++) {   // ripple row
+        std::vector<int> bits = cols[k];
+        if (carry_in >= 0) bits.push_back(carry_in);
+        carry_in = -1;
+        if (bits.empty()) { s.result[k] = s.zero_slot; continue; }
+        if (bits.size() == 1) { s.result[k] = bits[0]; continue; }
+        Level L;
+        if (bits.size() == 2) {      // half adder, selector a: sum = a ? !b : b, carry = a ? b : 0
+            L.sel.push_back({bits[0], -1});
+            s.result[k] = next++;
+            L.jobs.push_back({0, bits[1], 0, bits[1], 1, s.result[k]});
+            if (k < 15) { carry_in = next++; L.jobs.push_back({0, -1, 0, bits[1], 0, carry_in}); }
+        } else {
+            int sum, carry;
+            full_adder(L, bits[0], bits[1], bits[2], k, sum, carry);
+            s.result[k] = sum; carry_in = carry;
+        }
+        s.levels.push_back(L);
+    }
+    s.n_slots = next;
+    return s;
+}
+}  // namespace
+
+extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+{
+    if (!c || !lwe_bits || !out_lwe || n_values < 2 || (n_values & 1)) return fail("tx_inner_product_u16: need an even number of values");
+    if (!c->have_keys) return fail("tx_inner_product_u16: evaluation keys not loaded");
+    HIP_OK(hipSetDevice(c->device));
+    timing_reset(c);
+    const int P = (int)(n_values / 2);
+    IpSchedule s = ip_schedule(P);
+    size_t max_sel = 0, max_jobs = 0;
+    for (auto &L : s.levels) { max_sel = std::max(max_sel, L.sel.size()); max_jobs = std::max(max_jobs, L.jobs.size()); }
+    if (ensure_ws(c, (max_sel + 127) / 128)) return -1;
+    DevBuf pool, t, g0, g1, di0, di1, dsel, dc0, df0, dc1, df1, dout;
+    if (pool.alloc((size_t)s.n_slots * BIG * 8) || t.alloc(max_sel * BIG * 8) || g0.alloc(max_jobs * GL * 8) || g1.alloc(max_jobs * GL * 8) ||
+        di0.alloc(max_sel * 4) || di1.alloc(max_sel * 4) || dsel.alloc(max_jobs * 4) || dc0.alloc(max_jobs * 4) || df0.alloc(max_jobs * 4) ||
+        dc1.alloc(max_jobs * 4) || df1.alloc(max_jobs * 4) || dout.alloc(max_jobs * 4))
+        return fail("hipMalloc failed");
+    HIP_OK(hipMemsetAsync(pool.p, 0, (size_t)s.n_slots * BIG * 8, c->stream));
+    HIP_OK(hipMemcpyAsync(pool.p, lwe_bits, n_values * 16 * BIG * 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<int> hi0, hi1, hs, h0, hf0, h1, hf1, ho;
+    for (auto &L : s.levels) {
+        const int ns = (int)L.sel.size(), nj = (int)L.jobs.size();
+        hi0.resize(ns); hi1.resize(ns);
+        for (int i = 0; i < ns; i++) { hi0[i] = L.sel[i].first; hi1[i] = L.sel[i].second; }
+        hs.resize(nj); h0.resize(nj); hf0.resize(nj); h1.resize(nj); hf1.resize(nj); ho.resize(nj);
+        for (int i = 0; i < nj; i++) { hs[i] = L.jobs[i].sel; h0[i] = L.jobs[i].c0; hf0[i] = L.jobs[i].f0; h1[i] = L.jobs[i].c1; hf1[i] = L.jobs[i].f1; ho[i] = L.jobs[i].out; }
+        HIP_OK(hipMemcpyAsync(di0.p, hi0.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(di1.p, hi1.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(dsel.p, hs.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(dc0.p, h0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(df0.p, hf0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(dc1.p, h1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(df1.p, hf1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(dout.p, ho.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));           // host vectors are reused by the next level
+        hipLaunchKernelGGL(k_lwe_gather_add, dim3(ew_grid((size_t)ns * BIG)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                           (const int *)di0.p, (const int *)di1.p, (uint64_t *)t.p, ns);
+        run_cbs(c, (const uint64_t *)t.p, ns, c->ggsw_f);
+        hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                           (const int *)dc0.p, (const int *)df0.p, (uint64_t *)g0.p, nj);
+        hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                           (const int *)dc1.p, (const int *)df1.p, (uint64_t *)g1.p, nj);
+        ev_begin(c, F_LUT);
+        hipLaunchKernelGGL(k_cmux, dim3(grid_for(nj)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)g0.p, (const uint64_t *)g1.p,
+                           c->ggsw_f, (const int *)dsel.p, nj, c->tw);
+        ev_end(c);
+        hipLaunchKernelGGL(k_extract0_scatter, dim3(ew_grid((size_t)nj * BIG)), dim3(256), 0, c->stream, (const uint64_t *)g0.p,
+                           (const int *)dout.p, (uint64_t *)pool.p, nj);
+        HIP_OK(hipGetLastError());
+    }
+    for (int k = 0; k < 16; k++)     // MSB first
+        HIP_OK(hipMemcpyAsync(out_lwe + (size_t)(15 - k) * BIG, (uint64_t *)pool.p + (size_t)s.result[k] * BIG, BIG * 8,
+                              hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     timing_collect(c);
     return 0;

@@ -880,6 +880,48 @@ __global__ __launch_bounds__(256) void k_lwe_to_glwe(const uint64_t *lwe, uint64
         glwe[e] = v;
     }
 }
+// ---- bit-sliced arithmetic helpers (inner-product mini-workload) ----
+// t[u] = pool[i0[u]] + pool[i1[u]] (i1 < 0: copy): XOR of two encrypted bits at 2^63
+__global__ __launch_bounds__(256) void k_lwe_gather_add(const uint64_t *pool, const int *i0, const int *i1, uint64_t *out, int count)
+{
+    const size_t total = (size_t)count * BIG;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t u = e / BIG; int w = (int)(e % BIG);
+        uint64_t v = pool[(size_t)i0[u] * BIG + w];
+        if (i1[u] >= 0) v += pool[(size_t)i1[u] * BIG + w];
+        out[e] = v;
+    }
+}
+// GLWE with the bit of pool[src[u]] (+ 2^63 if flip[u]) in the constant coefficient; src < 0: zero
+__global__ __launch_bounds__(256) void k_build_glwe(const uint64_t *pool, const int *src, const int *flip, uint64_t *glwe, int count)
+{
+    const size_t total = (size_t)count * GL;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t u = e / GL; int w = (int)(e % GL), q = w / N, j = w % N;
+        uint64_t v = 0;
+        if (src[u] >= 0) {
+            const uint64_t *a = pool + (size_t)src[u] * BIG;
+            if (q < 2) v = (j == 0) ? a[q * N] : (uint64_t)0 - a[q * N + N - j];
+            else v = (j == 0) ? a[2 * N] : 0;
+        }
+        if (q == 2 && j == 0 && flip[u]) v += (uint64_t)1 << 63;
+        glwe[e] = v;
+    }
+}
+// sample extract at 0 from GLWE u into pool[dst[u]]
+__global__ __launch_bounds__(256) void k_extract0_scatter(const uint64_t *glwe, const int *dst, uint64_t *pool, int count)
+{
+    const size_t total = (size_t)count * BIG;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t u = e / BIG; int w = (int)(e % BIG);
+        const uint64_t *g = glwe + u * GL;
+        uint64_t v;
+        if (w == 2 * N) v = g[2 * N];
+        else { int q = w / N, m = w % N; v = (m == 0) ? g[q * N] : (uint64_t)0 - g[q * N + N - m]; }
+        pool[(size_t)dst[u] * BIG + w] = v;
+    }
+}
+
 // sample extract at 0 from GLWEs (batched)
 __global__ __launch_bounds__(256) void k_extract0(const uint64_t *glwe, uint64_t *lwe, int count)
 {

@@ -160,8 +160,9 @@ int server_encrypted_aes_decryption(int size)
     write_words(p.io + "/ciphertext_aes_download/result.bin", out);
     return 0;
 }
-int server_encrypted_compute(int size)
-{   // SRV_CMP:99-359 (mini-workload 0: max)
+int server_encrypted_compute(int size, int mini_workload)
+{   // SRV_CMP:99-359 (mini-workload 0: max); mini-workload 1 (inner product, cleartext_impl.py:65-70) has no
+    // server implementation in the reference
     Paths p(size);
     tx_params prm; tx_params_aes_tight(&prm);
     std::vector<uint64_t> in = read_words(p.io + "/ciphertext_aes_download/result.bin");
@@ -169,7 +170,8 @@ int server_encrypted_compute(int size)
     if (nvals == 0 || in.size() != nvals * 16 * big) throw std::runtime_error("lwe_ciphertext_list length is not a multiple of 16");
     tx_ctx *c = server_context(p, prm);
     std::vector<uint64_t> out(16 * big);
-    check(tx_max_u16(c, in.data(), nvals, out.data()), "tx_max_u16");
+    if (mini_workload == 1) check(tx_inner_product_u16(c, in.data(), nvals, out.data()), "tx_inner_product_u16");
+    else check(tx_max_u16(c, in.data(), nvals, out.data()), "tx_max_u16");
     tx_destroy(c);
     write_words(p.io + "/ciphertexts_download/result.bin", out);
     return 0;
@@ -189,7 +191,10 @@ int main(int argc, char **argv)
         if (name == "client_key_generation") return client_key_generation(size);
         if (name == "client_encode_encrypt") return client_encode_encrypt(size);
         if (name == "server_encrypted_aes_decryption") return server_encrypted_aes_decryption(size);
-        if (name == "server_encrypted_compute") return server_encrypted_compute(size);
+        if (name == "server_encrypted_compute") {   // optional 2nd argument / TX_MINI_WORKLOAD: 0 = max, 1 = inner product
+            const int mw = argc > 2 ? std::stoi(argv[2]) : (getenv("TX_MINI_WORKLOAD") ? atoi(getenv("TX_MINI_WORKLOAD")) : 0);
+            return server_encrypted_compute(size, mw);
+        }
         if (name == "client_decrypt_decode_aes_decryption") return client_decrypt(size, "ciphertext_aes_download", "decoded_result_aes.txt");
         if (name == "client_postprocess_aes_decryption") return client_postprocess(size, "decoded_result_aes.txt", "result_aes.txt");
         if (name == "client_decrypt_decode") return client_decrypt(size, "ciphertexts_download", "decoded_result.txt");

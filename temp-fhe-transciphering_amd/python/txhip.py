@@ -34,6 +34,7 @@ class TxTiming(C.Structure):
 
 EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys",
            "tx_load_round_luts", "tx_load_ctr_luts", "tx_transcipher", "tx_transcipher_partial", "tx_max_u16",
+           "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
            "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles"]
 
@@ -60,6 +61,7 @@ def lib():
         L.tx_transcipher.argtypes = [C.c_void_p, u8p, C.c_size_t, u8p, C.c_void_p, C.c_int]
         L.tx_transcipher_partial.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_int, u64p]
         L.tx_max_u16.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_inner_product_u16.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_stage_lwe_keyswitch.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_stage_blind_rotate.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_stage_extract_trace.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
@@ -147,6 +149,13 @@ class Engine:
         nv = lwe_bits.size // (16 * self.big)
         out = np.zeros(16 * self.big, np.uint64)
         self._chk(lib().tx_max_u16(self.h, _p64(lwe_bits), nv, _p64(out)))
+        return out.reshape(16, self.big)
+
+    def inner_product_u16(self, lwe_bits):
+        lwe_bits = np.ascontiguousarray(lwe_bits, np.uint64)
+        nv = lwe_bits.size // (16 * self.big)
+        out = np.zeros(16 * self.big, np.uint64)
+        self._chk(lib().tx_inner_product_u16(self.h, _p64(lwe_bits), nv, _p64(out)))
         return out.reshape(16, self.big)
 
     # ---- stage entry points ----

@@ -264,18 +264,19 @@ def test_client_library_keys_end_to_end(rig256):
     eng.close()
 
 
-@pytest.mark.parametrize("size", [0, 1])
-def test_stage_executables_end_to_end(size, tmp_path):
+@pytest.mark.parametrize("size,mw", [(0, 0), (1, 0), (0, 1)])
+def test_stage_executables_end_to_end(size, mw, tmp_path):
     """the harness contract: ten stage executables over datasets/ and io/, exact-equality verify
     (toy = ECB 1 block, small = CTR 8 blocks) incl. the max mini-workload"""
     import subprocess
     import sys as _sys
     root = os.path.dirname(HERE)
     rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_submission.py")
-    r = subprocess.run([_sys.executable, rs, str(size), "--root", str(tmp_path), "--seed", "123", "--fhe_seed", "99"],
+    r = subprocess.run([_sys.executable, rs, str(size), "--root", str(tmp_path), "--seed", "123", "--fhe_seed", "99",
+                        "--mini_workload", str(mw)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "AES decryption: PASS; max: PASS" in r.stdout
+    assert ("AES decryption: PASS; inner product: PASS" if mw else "AES decryption: PASS; max: PASS") in r.stdout
     name = ["toy", "small"][size]
     for d in ("public_keys", "ciphertexts_upload", "ciphertext_aes_download", "ciphertexts_download"):
         assert os.path.isdir(tmp_path / "io" / name / d)
@@ -296,3 +297,22 @@ def test_chunked_batches_match_unchunked(rig256):
     octr = r.eng.transcipher(ct, iv=AES_IV)
     import txdist
     assert np.array_equal(octr[129 * 128:], r.eng.transcipher(ct[16 * 129:], iv=txdist.iv_add(AES_IV, 129)))
+
+
+def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
+    """mini-workload 1: bit-identical to the oracle's circuit at n = 256; at full parameters the toy
+    fixture's inner_product.txt value (verify_result.py semantics) from the transciphered bits"""
+    r = rig256
+    vals = [0x1234, 0xFFFF, 0x0003, 0x8001]
+    bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+    ct = r.O.lwe_encrypt_bits(r.p, r.keys.glwe_sk, bits, r.p.glwe_std, seed=8)
+    out = r.eng.inner_product_u16(ct)
+    assert np.array_equal(out, r.octx.inner_product_u16(ct))
+    r = rig768
+    fx = [f for f in FIX if f["size"] == 0 and f["dataset_seed"] == 123][0]
+    st = r.eng.transcipher(bytes.fromhex(fx["db_hex"]))
+    ip = r.eng.inner_product_u16(st)
+    dec = r.O.lwe_decrypt_bits(r.keys.glwe_sk, ip)
+    assert int("".join(str(int(b)) for b in dec), 2) == fx["inner_product"]
+    with pytest.raises(Exception):
+        r.eng.inner_product_u16(st[:16 * 3])            # odd number of values

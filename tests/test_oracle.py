@@ -244,3 +244,18 @@ def test_max_tournament_and_reference_order_agree(small):
         out = ctx.max_u16(ct, tournament=tournament)
         dec = O.lwe_decrypt_bits(keys.glwe_sk, out)
         assert int("".join(str(int(b)) for b in dec), 2) == max(vals)
+
+
+def test_inner_product_bitsliced_circuit(small):
+    """mini-workload 1 (cleartext_impl.py:65-70): sum of pairwise products mod 2^16"""
+    p, keys, ctx = small
+    vals = [0x1234, 0xFFFF, 0x0003, 0x8001]
+    bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+    ct = O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=8)
+    out = ctx.inner_product_u16(ct)
+    dec = O.lwe_decrypt_bits(keys.glwe_sk, out)
+    half = len(vals) // 2
+    exp = sum((x * y) % 65536 for x, y in zip(vals[:half], vals[half:])) % 65536
+    assert int("".join(str(int(b)) for b in dec), 2) == exp
+    ph = O.lwe_phase(keys.glwe_sk, out)
+    assert np.abs(O.signed(ph - (dec.astype(np.uint64) << np.uint64(63)))).max() < 2 ** 60
