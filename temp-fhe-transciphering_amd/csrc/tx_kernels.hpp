@@ -764,23 +764,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint64_t *p0 = ct0 + (size_t)w.unit * GL;
     const uint64_t *p1 = ct1 + (size_t)w.unit * GL;
     const cplx *gg = ggsw_f + (size_t)sel[w.unit] * CBS_L * KP * KP * H;
+    cplx F[KP][8];
+    zero_f(F);
+#pragma unroll 1
+    for (int r = 0; r < KP; r++) {      // operands are read from global memory row by row, not held in registers
+        uint64_t lo[8], hi[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            lo[m] = p1[r * N + w.lane + 64 * m] - p0[r * N + w.lane + 64 * m];
+            hi[m] = p1[r * N + w.lane + 64 * m + 512] - p0[r * N + w.lane + 64 * m + 512];
+        }
+        extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
+    }
     uint64_t a0[KP][16];
 #pragma unroll
     for (int r = 0; r < KP; r++)
 #pragma unroll
         for (int m = 0; m < 16; m++) a0[r][m] = p0[r * N + w.lane + 64 * m];
-    cplx F[KP][8];
-    zero_f(F);
-#pragma unroll
-    for (int r = 0; r < KP; r++) {
-        uint64_t lo[8], hi[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            lo[m] = p1[r * N + w.lane + 64 * m] - a0[r][m];
-            hi[m] = p1[r * N + w.lane + 64 * m + 512] - a0[r][m + 8];
-        }
-        extprod_row<CBS_B, CBS_L, KP>(F, lo, hi, gg + (size_t)r * KP * H, (size_t)KP * KP * H, H, w);
-    }
     inv_add3(F, a0, w);
 #pragma unroll
     for (int r = 0; r < KP; r++)

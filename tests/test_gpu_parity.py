@@ -49,6 +49,13 @@ def rig256():
 
 
 @pytest.fixture(scope="module")
+def rig1024():
+    r = Rig(1024, 43)          # n = 1024: four output polynomials in the LWE key switch (kout = 4)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
 def rig768():
     r = Rig(768, 42)
     yield r
@@ -62,7 +69,7 @@ def test_twiddle_tables_identical(rig256):
     assert np.array_equal(rig256.eng.twiddles(), t)
 
 
-@pytest.mark.parametrize("which", ["rig256", "rig768"])
+@pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
 def test_stages_bit_identical_to_oracle(which, request):
     r = request.getfixturevalue(which)
     O, eng, octx, p, keys = r.O, r.eng, r.octx, r.p, r.keys
