@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void k_lwe_keyswitch(const uint64_t *in, uint6
 // ------------------------------------------------------------------------------------------
 // a5: multi-value blind rotation of the CBS test vector
 // (ggsw_conv.rs:250-300, pbs.rs:70-146).  One wave per input LWE; the accumulator (3 x 1024
-// torus words) stays in registers for all n CMux steps; bsk_f: [n][row 3][col 3][512] complex.
+// torus words) stays in the wave's LDS slice for all n CMux steps (the rotation X^a is a lane
+// permutation, so it has to pass through LDS anyway), the three digit transforms and the three
+// Fourier accumulators live in registers; bsk_f: [n][row 3][col 3][512] complex.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t test_vector(int i)
 {   // coefficient i in [0, N) of the accumulator built at ggsw_conv.rs:252-261
