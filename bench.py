@@ -200,7 +200,9 @@ def main():
             "setup_s": {"client_keygen": round(t_keygen, 2), "key_upload_and_transform": round(t_load, 3)},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.n, args.seed, min(os.cpu_count() or 1, 64))
+            # the GPU box gives one GPU's job a share of 16 host cores; never more threads than that
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(args.n, args.seed, max(1, min(avail, 16)))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
