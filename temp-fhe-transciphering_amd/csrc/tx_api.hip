@@ -674,8 +674,18 @@ extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t 
     timing_reset(c);
     const int P = (int)(n_values / 2);
     IpSchedule s = ip_schedule(P);
+    // a level is executed in chunks of at most IP_CHUNK selectors (one batched circuit bootstrap + one
+    // batched cmux launch per chunk) so that the Fourier GGSW workspace stays bounded (8 GiB)
+    const size_t IP_CHUNK = 16384;
     size_t max_sel = 0, max_jobs = 0;
-    for (auto &L : s.levels) { max_sel = std::max(max_sel, L.sel.size()); max_jobs = std::max(max_jobs, L.jobs.size()); }
+    for (auto &L : s.levels) {
+        for (size_t s0 = 0; s0 < L.sel.size(); s0 += IP_CHUNK) {
+            const size_t s1 = std::min(L.sel.size(), s0 + IP_CHUNK);
+            size_t nj = 0;
+            for (auto &j : L.jobs) if ((size_t)j.sel >= s0 && (size_t)j.sel < s1) nj++;
+            max_sel = std::max(max_sel, s1 - s0); max_jobs = std::max(max_jobs, nj);
+        }
+    }
     if (ensure_ws(c, (max_sel + 127) / 128)) return -1;
     DevBuf pool, t, g0, g1, di0, di1, dsel, dc0, df0, dc1, df1, dout;
     if (pool.alloc((size_t)s.n_slots * BIG * 8) || t.alloc(max_sel * BIG * 8) || g0.alloc(max_jobs * GL * 8) || g1.alloc(max_jobs * GL * 8) ||
@@ -686,34 +696,45 @@ extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t 
     HIP_OK(hipMemcpyAsync(pool.p, lwe_bits, n_values * 16 * BIG * 8, hipMemcpyHostToDevice, c->stream));
     std::vector<int> hi0, hi1, hs, h0, hf0, h1, hf1, ho;
     for (auto &L : s.levels) {
-        const int ns = (int)L.sel.size(), nj = (int)L.jobs.size();
-        hi0.resize(ns); hi1.resize(ns);
-        for (int i = 0; i < ns; i++) { hi0[i] = L.sel[i].first; hi1[i] = L.sel[i].second; }
-        hs.resize(nj); h0.resize(nj); hf0.resize(nj); h1.resize(nj); hf1.resize(nj); ho.resize(nj);
-        for (int i = 0; i < nj; i++) { hs[i] = L.jobs[i].sel; h0[i] = L.jobs[i].c0; hf0[i] = L.jobs[i].f0; h1[i] = L.jobs[i].c1; hf1[i] = L.jobs[i].f1; ho[i] = L.jobs[i].out; }
-        HIP_OK(hipMemcpyAsync(di0.p, hi0.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(di1.p, hi1.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(dsel.p, hs.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(dc0.p, h0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(df0.p, hf0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(dc1.p, h1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(df1.p, hf1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(dout.p, ho.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));           // host vectors are reused by the next level
-        hipLaunchKernelGGL(k_lwe_gather_add, dim3(ew_grid((size_t)ns * BIG)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
-                           (const int *)di0.p, (const int *)di1.p, (uint64_t *)t.p, ns);
-        run_cbs(c, (const uint64_t *)t.p, ns, c->ggsw_f);
-        hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
-                           (const int *)dc0.p, (const int *)df0.p, (uint64_t *)g0.p, nj);
-        hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
-                           (const int *)dc1.p, (const int *)df1.p, (uint64_t *)g1.p, nj);
-        ev_begin(c, F_LUT);
-        hipLaunchKernelGGL(k_cmux, dim3(grid_for(nj)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)g0.p, (const uint64_t *)g1.p,
-                           c->ggsw_f, (const int *)dsel.p, nj, c->tw);
-        ev_end(c);
-        hipLaunchKernelGGL(k_extract0_scatter, dim3(ew_grid((size_t)nj * BIG)), dim3(256), 0, c->stream, (const uint64_t *)g0.p,
-                           (const int *)dout.p, (uint64_t *)pool.p, nj);
-        HIP_OK(hipGetLastError());
+        size_t jpos = 0;                                   // jobs are ordered by selector index
+        for (size_t s0 = 0; s0 < L.sel.size(); s0 += IP_CHUNK) {
+            const size_t s1 = std::min(L.sel.size(), s0 + IP_CHUNK);
+            const int ns = (int)(s1 - s0);
+            size_t j1 = jpos;
+            while (j1 < L.jobs.size() && (size_t)L.jobs[j1].sel < s1) j1++;
+            const int nj = (int)(j1 - jpos);
+            hi0.resize(ns); hi1.resize(ns);
+            for (int i = 0; i < ns; i++) { hi0[i] = L.sel[s0 + i].first; hi1[i] = L.sel[s0 + i].second; }
+            hs.resize(nj); h0.resize(nj); hf0.resize(nj); h1.resize(nj); hf1.resize(nj); ho.resize(nj);
+            for (int i = 0; i < nj; i++) {
+                const Job &jb = L.jobs[jpos + i];
+                hs[i] = jb.sel - (int)s0; h0[i] = jb.c0; hf0[i] = jb.f0; h1[i] = jb.c1; hf1[i] = jb.f1; ho[i] = jb.out;
+            }
+            jpos = j1;
+            HIP_OK(hipMemcpyAsync(di0.p, hi0.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(di1.p, hi1.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(dsel.p, hs.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(dc0.p, h0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(df0.p, hf0.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(dc1.p, h1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(df1.p, hf1.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(dout.p, ho.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));       // host vectors are reused by the next chunk
+            hipLaunchKernelGGL(k_lwe_gather_add, dim3(ew_grid((size_t)ns * BIG)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                               (const int *)di0.p, (const int *)di1.p, (uint64_t *)t.p, ns);
+            run_cbs(c, (const uint64_t *)t.p, ns, c->ggsw_f);
+            hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                               (const int *)dc0.p, (const int *)df0.p, (uint64_t *)g0.p, nj);
+            hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
+                               (const int *)dc1.p, (const int *)df1.p, (uint64_t *)g1.p, nj);
+            ev_begin(c, F_LUT);
+            hipLaunchKernelGGL(k_cmux, dim3(grid_for(nj)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)g0.p, (const uint64_t *)g1.p,
+                               c->ggsw_f, (const int *)dsel.p, nj, c->tw);
+            ev_end(c);
+            hipLaunchKernelGGL(k_extract0_scatter, dim3(ew_grid((size_t)nj * BIG)), dim3(256), 0, c->stream, (const uint64_t *)g0.p,
+                               (const int *)dout.p, (uint64_t *)pool.p, nj);
+            HIP_OK(hipGetLastError());
+        }
     }
     for (int k = 0; k < 16; k++)     // MSB first
         HIP_OK(hipMemcpyAsync(out_lwe + (size_t)(15 - k) * BIG, (uint64_t *)pool.p + (size_t)s.result[k] * BIG, BIG * 8,

@@ -19,8 +19,8 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 BIN = os.path.join(os.path.dirname(HERE), "bin")
-NAMES = ["toy", "small", "medium"]
-DB_BOUND = [8, 64, 512]                     # harness/params.py:39
+NAMES = ["toy", "small", "medium", "large"]
+DB_BOUND = [8, 64, 512, 4096]               # harness/params.py:39; "large" (size 3) is this repo's definition, x8 again
 
 STAGES = [
     (3, "client_preprocess"), (4, "client_key_generation"), (5, "client_encode_encrypt"),
@@ -114,7 +114,7 @@ def run(size, root, seed=None, dataset_seed=None, fhe_seed=None, mini_workload=0
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("size", type=int, choices=[0, 1, 2])
+    ap.add_argument("size", type=int, choices=[0, 1, 2, 3])
     ap.add_argument("--root", default=os.getcwd())
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--fhe_seed", type=int, default=0)
