@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- AES blocks transciphered per second on the medium instance (BASELINE.json).
 
-One step = one pass of the hot path (tx_transcipher: rounds 10/9 by sample extraction, then 9 x
-[LWE key switch, blind rotation, trace, scheme switch, LUT CMux tree, linear layer]) over the
+One step = one pass of the hot path (tx_transcipher: first round by sample extraction from the
+encrypted tables, then 9 x [LWE key switch, blind rotation, trace, scheme switch, LUT CMux tree,
+linear layer]) over the
 medium instance's 64 AES blocks, sharded block-wise over the ranks (one process per GPU), keys and
 ciphertext bytes resident, result LWEs left in HBM and (N > 1) gathered to rank 0 with one RCCL
 gather.  Prints ONE JSON line on rank 0.
@@ -67,8 +68,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=64, help="AES blocks in the instance (medium = 64)")
     ap.add_argument("--n", type=int, default=768, help="small LWE dimension (AES_TIGHT: 768)")
-    ap.add_argument("--mode", choices=["ecb", "ctr"], default="ecb",
-                    help="ecb = the reference's inverse-cipher schedule; ctr = forward cipher on counters")
+    ap.add_argument("--mode", choices=["ecb", "ctr"], default="ctr",
+                    help="ctr = forward cipher on counter blocks, the mode the harness uses for the medium instance "
+                         "(aes_keygen_and_encrypt.py:49-55); ecb = the inverse-cipher schedule of the reference's own "
+                         "server_encrypted_aes_decryption.rs (same kernels, 4 instead of 3 LUT tables per round)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --blocks in total (the medium instance); weak: --blocks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
