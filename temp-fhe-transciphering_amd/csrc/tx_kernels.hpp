@@ -20,6 +20,12 @@ constexpr int CBS_B = 2, CBS_L = 7;
 constexpr int LOG_LUT = 3;
 constexpr int LOGN = 10;
 
+#ifdef TXD_PHASE_MARK   // diagnostic build: phase comments in the ISA, counted by tools/isa_phases.py
+#define TXD_PHASE(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; TXPHASE " #k ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TXD_PHASE(k) do {} while (0)
+#endif
+
 constexpr int WAVES = 4;                                   // units per workgroup
 constexpr size_t LDS_BYTES = (size_t)(TW_ROWS * 64 + WAVES * SCRATCH_CPLX) * sizeof(cplx);
 
@@ -388,6 +394,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds, BR_WAVE_BYTES);
     if (w.unit >= count) return;
+#ifdef TXD_EXP_ACTIVE_WAVES
+    if ((threadIdx.x >> 6) >= TXD_EXP_ACTIVE_WAVES) return;     // timing experiment only (profiles/README.md)
+#endif
     const uint64_t *ct = lwe + (size_t)w.unit * (n + 1);
     const int lane = w.lane;
     uint64_t *accl = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);   // [3][1024] in LDS
@@ -433,7 +442,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                        pbs_digit(((x[m + 8] ^ n1) - n1) - own[m + 8], thr));
             }
         }
+        TXD_PHASE(1);
         fft_fwd_n<KP>(d, w.tw, w.tile, lane);
+        TXD_PHASE(2);
         const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
         const int inext = (i + 1 < n) ? i + 1 : i;
         cplx F[KP][8];
@@ -451,7 +462,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int r = 0; r < 8; r++) g[r] = gn[r];
             }
+        TXD_PHASE(3);
         fft_inv_n<KP>(F, w.tw, w.tile, lane);
+        TXD_PHASE(4);
         wave_lds_fence();
 #pragma unroll
         for (int c = 0; c < KP; c++) {
