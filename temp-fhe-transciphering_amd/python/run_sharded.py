@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""One instance of the harness workload block-sharded over the GPUs of one node:
+transcipher + post-transcipher max + inner product, verified on rank 0 against the cleartext.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        temp-fhe-transciphering_amd/python/run_sharded.py <size> [--backend nccl|gloo]
+
+One process per GPU, a full replica of the evaluation keys on each (same FHE seed, no broadcast), contiguous
+slabs of AES blocks per rank; no collective on the data path of the transcipher.  Exchanges: one gather of the
+result LWEs, one gather of the partial maxima, and for the inner product one point-to-point step that brings
+every rank the remote operands of its pairs plus one gather of the partial sums (txdist.py).  With --backend
+gloo several ranks may share one GPU (rehearsal on a one-GPU box).  Dataset, key and IV derivation follow
+run_submission.py (harness/generate_dataset.py:26-29, aes_keygen_and_encrypt.py:34,42-55); sizes 1..3 are CTR.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+DB_BOUND = [8, 64, 512, 4096]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("size", type=int, choices=[0, 1, 2, 3])
+    ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--fhe_seed", type=int, default=99)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--n", type=int, default=768, help="LWE dimension (AES_TIGHT: 768)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import txhip
+    import txclient
+    import txdist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("run_sharded.py needs a HIP device; there is no CPU fallback")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    d = dist if world > 1 else None
+
+    np.random.seed(args.seed)
+    db = np.random.randint(0, 65536, size=DB_BOUND[args.size], dtype=np.uint16)
+    key = hashlib.sha256(str(args.seed).encode()).digest()[:16]
+    iv = hashlib.sha256(b"iv" + str(args.seed).encode()).digest()[:16] if args.size else None
+    pt = b"".join(int(v).to_bytes(2, "big") for v in db)
+    ct = txclient.aes_ctr_crypt(key, iv, pt) if args.size else txclient.aes_ecb_encrypt(key, pt)
+    n_blocks, n_values = len(ct) // 16, len(db)
+
+    p = txhip.aes_tight(n=args.n)
+    keys = txclient.ClientKeys(p, seed=args.fhe_seed)
+    eng = txhip.Engine(p, device=dev_index)
+    eng.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
+    if args.size:
+        eng.load_ctr_luts(keys.ctr_luts(key, seed=args.fhe_seed + 1))
+    else:
+        eng.load_round_luts(keys.round_luts(key, seed=args.fhe_seed + 1))
+    words = eng.big
+
+    def to_t(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(cdev)
+
+    def to_np(t):
+        return np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+
+    kept = {}
+
+    def local_fn(ct_slab, iv_slab, n_local, n_pad):
+        out = torch.zeros((n_pad * 128, words), dtype=torch.int64, device=cdev)
+        if n_local:
+            out[: n_local * 128] = to_t(eng.transcipher(ct_slab, iv_slab))
+        kept["mine"], kept["n"] = out, n_local
+        return out
+
+    def sync():
+        if d is not None:
+            d.barrier()
+        torch.cuda.synchronize()
+
+    t = {}
+    sync(); t0 = time.perf_counter()
+    res = txdist.transcipher_sharded(local_fn, ct, iv, rank, world, d)
+    sync(); t["transcipher_s"] = time.perf_counter() - t0
+    mine, n_local_values = kept["mine"], kept["n"] * 8
+
+    t0 = time.perf_counter()
+    mx = txdist.max_sharded(lambda x: to_t(eng.max_u16(to_np(x))), mine, n_local_values, rank, world, d)
+    sync(); t["max_s"] = time.perf_counter() - t0
+
+    ranges = [(8 * s, 8 * c) for s, c in (txdist.shard(n_blocks, world, r) for r in range(world))]
+    t0 = time.perf_counter()
+    ip = txdist.inner_product_sharded(lambda x: to_t(eng.inner_product_u16(to_np(x))), mine[: n_local_values * 16],
+                                      ranges, n_values, rank, world, d)
+    sync(); t["inner_product_s"] = time.perf_counter() - t0
+
+    ok = True
+    if rank == 0:
+        vals = [int(v) for v in db]
+        half = len(vals) // 2
+        got = txclient.bits_to_u16(keys.decrypt_bits(to_np(res)))
+        got_max = int(txclient.bits_to_u16(keys.decrypt_bits(to_np(mx)))[0])
+        got_ip = int(txclient.bits_to_u16(keys.decrypt_bits(to_np(ip)))[0])
+        exp_ip = sum((vals[i] * vals[i + half]) % 65536 for i in range(half)) % 65536
+        checks = {"aes": bool(np.array_equal(got, db)), "max": got_max == max(vals), "inner_product": got_ip == exp_ip}
+        ok = all(checks.values())
+        print(json.dumps({"size": args.size, "values": n_values, "blocks": n_blocks, "ranks": world, "backend": args.backend,
+                          "checks": checks, **{k: round(v, 4) for k, v in t.items()}}), flush=True)
+    if d is not None:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+        d.broadcast(flag, src=0)
+        ok = bool(flag.item())
+        d.destroy_process_group()
+    eng.close()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -65,3 +65,85 @@ def max_sharded(local_max_fn, local_lwe_bits, n_local_values, rank, world, dist=
     dist.gather(buf, gather_list=None, dst=0)
     dist.gather(have, gather_list=None, dst=0)
     return None
+
+
+def pair_shard(n_values, world, rank):
+    """pairs (p, p + n/2), p in [start, start + count), handled by rank `rank`"""
+    return shard(n_values // 2, world, rank)
+
+
+def _overlap(a0, a1, b0, b1):
+    lo, hi = max(a0, b0), min(a1, b1)
+    return (lo, hi) if hi > lo else None
+
+
+def inner_product_sharded(local_ip_fn, local_lwe_bits, ranges, n_values, rank, world, dist=None):
+    """Inner-product mini-workload (harness/cleartext_impl.py:65-70) across ranks.
+
+    Rank k holds the LWE bits of the contiguous values ranges[k] = (start, count) (the layout the sharded
+    transcipher leaves behind: 16 rows per value).  The n/2 pairs (p, p + n/2) are dealt out evenly; ONE
+    point-to-point exchange step brings every rank the operands of its pairs that live elsewhere, every rank
+    computes its partial sum with local_ip_fn(tensor[2m*16, words]) -> tensor[16, words], the partial sums
+    (16 LWEs each) are gathered to rank 0, and rank 0 adds them with one more call of the same circuit on
+    (s_0, ..., s_{G-1}, 1, ..., 1), the ones being trivial ciphertexts.  Returns the 16 LWEs on rank 0."""
+    import torch
+    half = n_values // 2
+    words = local_lwe_bits.shape[1]
+    my0, myc = ranges[rank]
+    if world == 1 or dist is None:
+        return local_ip_fn(local_lwe_bits[: n_values * 16])
+
+    def wanted(r):
+        """value intervals rank r needs, in the order it concatenates them"""
+        ps, pc = pair_shard(n_values, world, r)
+        return [(ps, ps + pc), (ps + half, ps + half + pc)] if pc else []
+
+    # ---- one exchange step: rows this rank owns and another rank needs, and vice versa
+    ops, recv_slots, sends = [], [], []
+    ps, pc = pair_shard(n_values, world, rank)
+    mine = torch.zeros((2 * pc * 16, words), dtype=local_lwe_bits.dtype, device=local_lwe_bits.device)
+    for part, (w0, w1) in enumerate(wanted(rank)):
+        for k in range(world):
+            ov = _overlap(w0, w1, ranges[k][0], ranges[k][0] + ranges[k][1])
+            if ov is None:
+                continue
+            dst = mine[(part * pc + ov[0] - w0) * 16:(part * pc + ov[1] - w0) * 16]
+            if k == rank:
+                dst.copy_(local_lwe_bits[(ov[0] - my0) * 16:(ov[1] - my0) * 16])
+            else:
+                buf = torch.empty_like(dst)
+                recv_slots.append((dst, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, k))
+    for r in range(world):
+        if r == rank:
+            continue
+        for (w0, w1) in wanted(r):
+            ov = _overlap(w0, w1, my0, my0 + myc)
+            if ov is not None:
+                t = local_lwe_bits[(ov[0] - my0) * 16:(ov[1] - my0) * 16].contiguous()
+                sends.append(t)
+                ops.append(dist.P2POp(dist.isend, t, r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for dst, buf in recv_slots:
+        dst.copy_(buf)
+
+    # ---- partial sums, gathered to rank 0
+    part = local_ip_fn(mine) if pc else None
+    buf = part if part is not None else torch.zeros((16, words), dtype=local_lwe_bits.dtype, device=local_lwe_bits.device)
+    have = torch.tensor([1 if part is not None else 0], dtype=torch.int64, device=local_lwe_bits.device)
+    if rank != 0:
+        dist.gather(buf, gather_list=None, dst=0)
+        dist.gather(have, gather_list=None, dst=0)
+        return None
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    flags = [torch.empty_like(have) for _ in range(world)]
+    dist.gather(buf, gather_list=parts, dst=0)
+    dist.gather(have, gather_list=flags, dst=0)
+    sums = [p for p, f in zip(parts, flags) if int(f.item()) == 1]
+    if len(sums) == 1:
+        return sums[0]
+    ones = torch.zeros((len(sums) * 16, words), dtype=buf.dtype, device=buf.device)
+    ones[15::16, words - 1] = -(1 << 63)                    # value 1, MSB first: only bit 15 set, at 2^63, mask 0
+    return local_ip_fn(torch.cat(sums + [ones], dim=0))

@@ -323,3 +323,22 @@ def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
     assert int("".join(str(int(b)) for b in dec), 2) == fx["inner_product"]
     with pytest.raises(Exception):
         r.eng.inner_product_u16(st[:16 * 3])            # odd number of values
+
+
+@pytest.mark.gpu
+def test_sharded_runner_two_ranks_share_one_gpu():
+    """N > 1 path with the real engine: two ranks (gloo, both on cuda:0) shard the small instance; transcipher,
+    max (gather of partial maxima) and inner product (one point-to-point exchange + gather of partial sums)
+    all decrypt to the cleartext values on rank 0 (run_sharded.py exits non-zero otherwise)"""
+    import subprocess
+    import sys as _sys
+    import json as _json
+    root = os.path.dirname(HERE)
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_sharded.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29650 + os.getpid() % 100), rs, "1",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert _json.loads(line)["checks"] == {"aes": True, "max": True, "inner_product": True}

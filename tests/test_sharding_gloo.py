@@ -91,3 +91,50 @@ def test_two_rank_sharded_transcipher_gloo(mode):
         p.join(timeout=600)
         assert p.exitcode == 0
     assert ok
+
+
+def _ip_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import txdist
+    p = O.aes_tight(n=256)
+    keys = O.Keys(p, seed=33)
+    ctx = O.Ctx(keys, threads=4)
+    vals = [0x1234, 0xFFFF, 0x0003, 0x8001]                  # rank 0 holds values 0-1, rank 1 values 2-3
+    bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+    ct = torch.from_numpy(O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=8).view(np.int64))
+    ranges = [(0, 2), (2, 2)]
+    local = ct[ranges[rank][0] * 16:(ranges[rank][0] + ranges[rank][1]) * 16].clone()
+
+    def local_ip(t):
+        return torch.from_numpy(ctx.inner_product_u16(np.ascontiguousarray(t.numpy().view(np.uint64))).view(np.int64))
+
+    out = txdist.inner_product_sharded(local_ip, local, ranges, len(vals), rank, world, dist)
+    if rank == 0:
+        dec = O.lwe_decrypt_bits(keys.glwe_sk, out.numpy().view(np.uint64))
+        exp = sum((x * y) % 65536 for x, y in zip(vals[:2], vals[2:])) % 65536
+        q.put(int("".join(str(int(b)) for b in dec), 2) == exp)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_inner_product_gloo():
+    """pairs dealt out over the ranks, one point-to-point exchange of the remote operands, partial sums
+    gathered and added by the same circuit on rank 0 (txdist.inner_product_sharded)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_ip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert ok
