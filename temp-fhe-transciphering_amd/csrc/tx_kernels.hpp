@@ -494,95 +494,191 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // switch with the 41/23-bit split key)   (ggsw_conv.rs:304-316, automorphism.rs:134-233,
 // fourier_glwe_keyswitch.rs:213-342).  auto_f: [split 2][idx 10][q 2][lev 3][col 3][512].
 // ------------------------------------------------------------------------------------------
-// LDS of the trace kernels: twiddles, then per wave: transpose tile + two parked polynomials
-constexpr size_t TRACE_WAVE_BYTES = SCRATCH_CPLX * sizeof(cplx) + 2 * N * sizeof(uint64_t);
-constexpr size_t LDS_BYTES_TRACE = TW_ROWS * 64 * sizeof(cplx) + WAVES * TRACE_WAVE_BYTES;
+// LDS of the trace kernels: twiddles, then per wave: transpose tile + the GLWE being traced
+// (3 x 1024 torus words, natural order) -- same footprint as the blind rotation, one workgroup per CU.
+constexpr size_t TRACE_WAVE_BYTES = BR_WAVE_BYTES;
+constexpr size_t LDS_BYTES_TRACE = LDS_BYTES_BR;
+constexpr int TRACE_KEYS_PASS = 2 * AUTO_L * KP;            // key polynomials per pass over one key split (18)
 
-// scatter polynomial p (registers) as p(X^t) into `dst` (LDS, natural order)
-__device__ __forceinline__ void automorph_to_lds(const uint64_t (&p)[16], uint64_t *dst, uint32_t t, int lane)
+// The automorphism keys are the same for every unit and the four waves of a workgroup walk them in the same
+// order; streamed per wave, a pass is L2->CU fill bound (4 x 144 KB per CU against ~30 B/clk/CU).  So the
+// workgroup fetches every key polynomial ONCE: during a pass the four transpose tiles are idle and serve as a
+// 4-slot ring; each wave copies a quarter of a key polynomial straight into a slot with two LDS-DMA loads
+// (global_load_lds_dwordx4: no staging registers), three polynomials ahead, and all four waves read the slot
+// (8 x ds_read_b128).  One s_barrier per key polynomial keeps the waves in step; it waits for this wave's LDS
+// traffic and for all but the youngest DMA loads.  A barrier before the first DMA (every wave has finished its
+// forward transforms) and one after the last read (before the inverse transforms) fence the tiles' two uses.
+struct KeyRing {
+    unsigned char *slot0;       // wave 0's tile; slot s = slot0 + s * TRACE_WAVE_BYTES
+    uint32_t slot0_addr;        // the same as an LDS byte address (for M0)
+    const cplx *auto_f;
+    size_t split_stride;
+    int wave, lane;
+};
+__device__ __forceinline__ cplx *ring_slot(const KeyRing &k, int s)
 {
-    wave_lds_fence();
+    return reinterpret_cast<cplx *>(k.slot0 + (size_t)s * TRACE_WAVE_BYTES);
+}
+// key polynomial j of pass (idx, split): (q, level finest first, column)
+__device__ __forceinline__ const cplx *trace_key(const KeyRing &k, int idx, int split, int j)
+{
+    const int q = j / (AUTO_L * KP), i = (j / KP) % AUTO_L, c = j % KP;
+    return k.auto_f + (size_t)split * k.split_stride + ((((size_t)idx * 2 + q) * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * H;
+}
+// one LDS-DMA load: 64 lanes x 16 B from per-lane global addresses to LDS [m0, m0 + 1 KiB).  In asm so that hipcc
+// does not count it: with the builtin it drains every DMA in flight (vmcnt(0)) before each read of a ring slot.
+__device__ __forceinline__ void glds16(const cplx *src, uint32_t lds_addr)
+{
+#ifdef TXD_ABL_NODMA
+    return;
+#endif
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void ring_dma(const KeyRing &k, const cplx *poly, int slot)
+{
+    const cplx *src = poly + k.wave * 128 + k.lane;
+    const uint32_t dst = k.slot0_addr + (uint32_t)slot * (uint32_t)TRACE_WAVE_BYTES + (uint32_t)k.wave * 2048u;   // wave-uniform
+    glds16(src, dst);
+    glds16(src + 64, dst + 1024u);
+}
+// this wave's LDS traffic done and all but its VM youngest DMA loads landed, then the workgroup barrier
+template <int VM>
+__device__ __forceinline__ void ring_barrier()
+{
+#ifdef TXD_ABL_NOBAR
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(VM) : "memory");
+#endif
+}
+
+template <int J>
+__device__ __forceinline__ void ring_step(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_L][8], const KeyRing &k, int idx, int split)
+{
+    constexpr int ahead = (TRACE_KEYS_PASS - 1 - J < 2) ? TRACE_KEYS_PASS - 1 - J : 2;     // polynomials issued after J
+    ring_barrier<2 * ahead>();                              // polynomial J landed everywhere; slot (J-1)%4 free
+    cplx g[8];
+    const cplx *sl = ring_slot(k, J % 4);
 #pragma unroll
-    for (int m = 0; m < 16; m++) {
-        uint32_t i = lane + 64 * m;
-        uint32_t it = i * t;
-        uint64_t neg = (uint64_t)0 - (uint64_t)((it >> LOGN) & 1);
-        dst[it & (N - 1)] = (p[m] ^ neg) - neg;
+    for (int r = 0; r < 8; r++) g[r] = sl[r * 64 + k.lane];
+    if (J + 3 < TRACE_KEYS_PASS) ring_dma(k, trace_key(k, idx, split, J + 3), (J + 3) % 4);
+    fmac8r(F[J % KP], Dg[J / KP], g);
+}
+// one pass over a key split: F[c] = sum over the six digit transforms of D * key, in the oracle's order
+__device__ __forceinline__ void ring_pass(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_L][8], const KeyRing &k, int idx, int split)
+{
+    static_assert(TRACE_KEYS_PASS == 18, "unrolled for 18 key polynomials per pass");
+    ring_barrier<0>();                                      // every wave is done with its tile
+    ring_dma(k, trace_key(k, idx, split, 0), 0);
+    ring_dma(k, trace_key(k, idx, split, 1), 1);
+    ring_dma(k, trace_key(k, idx, split, 2), 2);
+    ring_step<0>(F, Dg, k, idx, split);   ring_step<1>(F, Dg, k, idx, split);   ring_step<2>(F, Dg, k, idx, split);
+    ring_step<3>(F, Dg, k, idx, split);   ring_step<4>(F, Dg, k, idx, split);   ring_step<5>(F, Dg, k, idx, split);
+    ring_step<6>(F, Dg, k, idx, split);   ring_step<7>(F, Dg, k, idx, split);   ring_step<8>(F, Dg, k, idx, split);
+    ring_step<9>(F, Dg, k, idx, split);   ring_step<10>(F, Dg, k, idx, split);  ring_step<11>(F, Dg, k, idx, split);
+    ring_step<12>(F, Dg, k, idx, split);  ring_step<13>(F, Dg, k, idx, split);  ring_step<14>(F, Dg, k, idx, split);
+    ring_step<15>(F, Dg, k, idx, split);  ring_step<16>(F, Dg, k, idx, split);  ring_step<17>(F, Dg, k, idx, split);
+    ring_barrier<0>();                                      // every wave has read the last slot: tiles free again
+}
+
+// One trace on the GLWE held in LDS (gl = [3][1024], natural order): for idx = 0..9, t = N/2^idx + 1:
+// g += KS_t(g(X^t)).  Per step: the permuted mask p(X^t) is GATHERED from LDS (coefficient i of p(X^t) is
+// +-p[i * t^-1 mod 2N]; an odd stride keeps ds_read_b64 conflict-free), decomposed, and its six digit
+// polynomials are transformed ONCE; they stay live (the register allocator parks them in the accumulation
+// registers, idle at one wave per SIMD) across the two passes over the split key (low 41 bits, high 23 bits);
+// each pass = 18 key polynomials from the shared ring, three inverse transforms and a read-modify-write of g.
+__device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, const WaveCtx &w)
+{
+    typedef Decomp<AUTO_B, AUTO_L> D;
+    constexpr int NP = 2 * AUTO_L;                 // digit polynomials per step
+    const int lane = w.lane;
+#pragma unroll 1
+    for (int idx = 0; idx < LOGN; idx++) {
+        const uint32_t t = (N >> idx) + 1;
+        uint32_t tinv = t;                         // t * t = 1 mod 8; two Newton steps => mod 2^12 >= 2N
+        tinv *= 2u - t * tinv;
+        tinv *= 2u - t * tinv;
+        cplx Dg[NP][8];
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint64_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = gl[q * N + ((((uint32_t)(lane + 64 * m)) * tinv) & (N - 1))];
+            issue_fence();
+            D::state_t st[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint64_t neg = (uint64_t)0 - (uint64_t)(((((uint32_t)(lane + 64 * m)) * tinv) >> LOGN) & 1);
+                st[m] = D::init((x[m] ^ neg) - neg);
+            }
+            cplx d[AUTO_L][8];
+#pragma unroll
+            for (int i = 0; i < AUTO_L; i++) {
+                const D::state_t tie = (i == AUTO_L - 1) ? D::tie_mask(lane) : (D::state_t)0;
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+                    d[i][m] = make_double2((double)D::next(st[m], tie), (double)D::next(st[m + 8], tie));
+            }
+            fft_fwd_n<AUTO_L>(d, w.tw, w.tile, lane);
+#pragma unroll
+            for (int i = 0; i < AUTO_L; i++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) Dg[q * AUTO_L + i][r] = d[i][r];
+        }
+        {   // body: g[2] += g[2](X^t)   (the key switch output starts as (0, 0, permuted body))
+            uint64_t *b = gl + 2 * N;
+            uint64_t own[16], pb[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) own[m] = b[lane + 64 * m];
+#pragma unroll
+            for (int m = 0; m < 16; m++) pb[m] = b[(((uint32_t)(lane + 64 * m)) * tinv) & (N - 1)];
+            issue_fence();
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint64_t neg = (uint64_t)0 - (uint64_t)(((((uint32_t)(lane + 64 * m)) * tinv) >> LOGN) & 1);
+                b[lane + 64 * m] = own[m] + ((pb[m] ^ neg) - neg);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            cplx F[KP][8];
+            zero_f(F);
+            ring_pass(F, Dg, ring, idx, s);
+            fft_inv_n<KP>(F, w.tw, w.tile, lane);
+            const int sh = s ? AUTO_SPLIT : 0;
+            wave_lds_fence();
+#pragma unroll
+            for (int c = 0; c < KP; c++) {
+                uint64_t *a = gl + c * N;
+                uint64_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = a[lane + 64 * m];
+                issue_fence();
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    a[lane + 64 * m] = cur[m] + (f64_to_torus(F[c][m].x) << sh);
+                    a[lane + 64 * (m + 8)] = cur[m + 8] + (f64_to_torus(F[c][m].y) << sh);
+                }
+            }
+        }
     }
     wave_lds_fence();
 }
 
-// one trace on the GLWE held in g[3][16]: for i = 1..10, t = N/2^(i-1)+1: g += KS_t(g(X^t)).
-// The key switch runs once per key split (low 41 bits, high 23 bits), re-deriving the digit
-// transforms from the permuted mask kept in LDS, so that only three Fourier accumulators are live.
-__device__ __forceinline__ void trace_regs(uint64_t (&g)[KP][16], const cplx *auto_f, size_t split_stride,
-                                           uint64_t *park, const WaveCtx &w)
+__device__ __forceinline__ KeyRing ring_setup(unsigned char *lds, const cplx *auto_f, size_t split_stride)
 {
-    typedef Decomp<AUTO_B, AUTO_L> D;
-#pragma unroll 1
-    for (int idx = 0; idx < LOGN; idx++) {
-        const uint32_t t = (N >> idx) + 1;
-        automorph_to_lds(g[0], park, t, w.lane);
-        automorph_to_lds(g[1], park + N, t, w.lane);
-        // decompose the permuted mask once; park the three signed 13-bit digits of every coefficient
-        // packed in 16-bit fields (finest level in bits 0-15) for the two passes over the split key
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            uint64_t *pw = park + q * N;
-            uint64_t x[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) x[m] = pw[w.lane + 64 * m];
-            issue_fence();
-#pragma unroll
-            for (int m = 0; m < 16; m++) {
-                D::state_t st = D::init(x[m]);
-                uint64_t pk = 0;
-#pragma unroll
-                for (int i = 0; i < AUTO_L; i++)
-                    pk |= (uint64_t)(uint16_t)(int16_t)D::next(st, (i == AUTO_L - 1) ? D::tie_mask(w.lane) : (D::state_t)0) << (16 * i);
-                pw[w.lane + 64 * m] = pk;
-            }
-        }
-        {   // body: g[2] += g[2](X^t)   (keyswitch output starts as (0, 0, permuted body))
-            automorph_to_lds(g[2], w.pl, t, w.lane);
-            uint64_t pb[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) pb[m] = w.pl[w.lane + 64 * m];
-#pragma unroll
-            for (int m = 0; m < 16; m++) g[2][m] += pb[m];
-            wave_lds_fence();
-        }
-#pragma unroll 1
-        for (int s = 0; s < 2; s++) {
-            cplx F[KP][8];
-            zero_f(F);
-#pragma unroll 1
-            for (int q = 0; q < 2; q++) {
-                const uint64_t *pw = park + q * N;
-                uint64_t pk[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) pk[m] = pw[w.lane + 64 * m];
-                issue_fence();
-                cplx d[AUTO_L][8];
-#pragma unroll
-                for (int i = 0; i < AUTO_L; i++)
-#pragma unroll
-                    for (int m = 0; m < 8; m++)
-                        d[i][m] = make_double2((double)(int16_t)(pk[m] >> (16 * i)), (double)(int16_t)(pk[m + 8] >> (16 * i)));
-                const cplx *key = auto_f + (size_t)s * split_stride + (((size_t)idx * 2 + q) * AUTO_L) * KP * H;
-                mac_group<AUTO_L, KP>(F, d, AUTO_L - 1, key, (size_t)KP * H, H, w);
-            }
-            fft_inv_n<KP>(F, w.tw, w.tile, w.lane);
-            const int sh = s ? AUTO_SPLIT : 0;
-#pragma unroll
-            for (int c = 0; c < KP; c++)
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    g[c][m] += f64_to_torus(F[c][m].x) << sh;
-                    g[c][m + 8] += f64_to_torus(F[c][m].y) << sh;
-                }
-        }
-    }
+    KeyRing k;
+    k.slot0 = lds + TW_ROWS * 64 * sizeof(cplx);
+    k.slot0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)k.slot0);
+    k.auto_f = auto_f;
+    k.split_stride = split_stride;
+    k.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    k.lane = (int)(threadIdx.x & 63);
+    return k;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_extract_trace(const uint64_t *acc, uint64_t *glev, int count,
@@ -590,12 +686,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds, TRACE_WAVE_BYTES);
-    uint64_t *park = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
-    if (w.unit >= count * CBS_L) return;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
+    const bool active = w.unit < count * CBS_L;     // idle waves of the last workgroup redo the last unit (in their
+    if (!active) w.unit = count * CBS_L - 1;        // own LDS): every wave takes part in the key ring's barriers
     const int ctx = w.unit / CBS_L, lvl = w.unit % CBS_L;         // lvl = level - 1 = rotation k
     const uint64_t *a = acc + (size_t)ctx * GL;
     const int lane = w.lane;
-    uint64_t g[KP][16];
     // buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const:
     //   mask: g[j] = buf[0] >> 10 (j = 0), -((-buf[j]) >> 10) otherwise; body: (buf[0] + c) >> 10, 0...
 #pragma unroll
@@ -604,17 +700,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int m = 0; m < 16; m++) {
             int j = lane + 64 * m, s = j + lvl;
             uint64_t x = (s < N) ? a[q * N + s] : (uint64_t)0 - a[q * N + s - N];
-            g[q][m] = (j == 0) ? (x >> LOGN) : (uint64_t)0 - (((uint64_t)0 - x) >> LOGN);
+            gl[q * N + j] = (j == 0) ? (x >> LOGN) : (uint64_t)0 - (((uint64_t)0 - x) >> LOGN);
         }
+    {
+        const uint64_t b0 = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
 #pragma unroll
-    for (int m = 0; m < 16; m++) g[2][m] = 0;
-    if (lane == 0) g[2][0] = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
-    trace_regs(g, auto_f, split_stride, park, w);
+        for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing older than the ring's DMA on the VM counter
+    const KeyRing ring = ring_setup(lds, auto_f, split_stride);
+    trace_lds(gl, ring, w);
+    if (!active) return;
     uint64_t *o = glev + (size_t)w.unit * GL;
 #pragma unroll
     for (int q = 0; q < KP; q++)
 #pragma unroll
-        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = g[q][m];
+        for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = gl[q * N + lane + 64 * m];
 }
 
 // trace_assign alone on `count` GLWEs in place (unit parity for a7)
@@ -623,19 +724,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds, TRACE_WAVE_BYTES);
-    uint64_t *park = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
-    if (w.unit >= count) return;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);
+    const bool active = w.unit < count;
+    if (!active) w.unit = count - 1;
     uint64_t *p = glwe + (size_t)w.unit * GL;
-    uint64_t g[KP][16];
 #pragma unroll
     for (int q = 0; q < KP; q++)
 #pragma unroll
-        for (int m = 0; m < 16; m++) g[q][m] = p[q * N + w.lane + 64 * m];
-    trace_regs(g, auto_f, split_stride, park, w);
+        for (int m = 0; m < 16; m++) gl[q * N + w.lane + 64 * m] = p[q * N + w.lane + 64 * m];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const KeyRing ring = ring_setup(lds, auto_f, split_stride);
+    trace_lds(gl, ring, w);
+    if (!active) return;
 #pragma unroll
     for (int q = 0; q < KP; q++)
 #pragma unroll
-        for (int m = 0; m < 16; m++) p[q * N + w.lane + 64 * m] = g[q][m];
+        for (int m = 0; m < 16; m++) p[q * N + w.lane + 64 * m] = gl[q * N + w.lane + 64 * m];
 }
 
 // ------------------------------------------------------------------------------------------
