@@ -245,19 +245,39 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
     }
 }
 
-// round-half-even(x) mod 2^64 in 7 f64 operations + 1 integer add3 (oracle f64_to_torus)
-__device__ __forceinline__ uint64_t f64_to_torus(double x)
+// round-half-even(x) mod 2^64 (oracle f64_to_torus) as the two dwords of the result.  Same values as
+//   m = x 2^-64;  y = m - rint(m);  t1 = fma(y, 2^64, 1.5 2^84);  h = t1 - 1.5 2^84;  lo = fma(y, 2^64, -h);
+//   t2 = lo + 1.5 2^52;  result = (bits(t1).lo + bits(t2).hi - 0x43380000) : bits(t2).lo
+// with y 2^64 formed exactly as x - rint(m) 2^64 (one fma whose destination is the dead x), so that the two
+// fmas with a non-inline addend -- each of which costs two v_mov to re-materialise the constant it overwrites --
+// become plain adds against constants the compiler can keep in scalar registers.
+__device__ __forceinline__ void f64_to_torus2(double x, uint32_t &rlo, uint32_t &rhi)
 {
-    double m = x * 0x1p-64;
-    double y = m - __builtin_rint(m);
-    double t1 = __builtin_fma(y, 0x1p64, 0x1.8p84);
+    double r = __builtin_rint(x * 0x1p-64);
+    double ys = __builtin_fma(r, -0x1p64, x);               // = (m - rint(m)) 2^64, exact
+    double t1 = ys + 0x1.8p84;
     double h = t1 - 0x1.8p84;
-    double lo = __builtin_fma(y, 0x1p64, -h);
+    double lo = ys - h;
     double t2 = lo + 0x1.8p52;
     uint64_t b1 = (uint64_t)__double_as_longlong(t1), b2 = (uint64_t)__double_as_longlong(t2);
-    uint32_t rlo = (uint32_t)b2;
-    uint32_t rhi = (uint32_t)b1 + (uint32_t)(b2 >> 32) - 0x43380000u;
+    rlo = (uint32_t)b2;
+    rhi = (uint32_t)b1 + (uint32_t)(b2 >> 32) - 0x43380000u;
+}
+__device__ __forceinline__ uint64_t f64_to_torus(double x)
+{
+    uint32_t rlo, rhi;
+    f64_to_torus2(x, rlo, rhi);
     return ((uint64_t)rhi << 32) | rlo;
+}
+// cur + round(x) mod 2^64 with the carry handled on dwords (no 64-bit pair has to be assembled by v_mov)
+__device__ __forceinline__ uint64_t torus_add_f64(uint64_t cur, double x)
+{
+    uint32_t rlo, rhi;
+    f64_to_torus2(x, rlo, rhi);
+    const uint32_t cl = (uint32_t)cur, ch = (uint32_t)(cur >> 32);
+    const uint32_t nl = cl + rlo;
+    const uint32_t nh = ch + rhi + (uint32_t)(nl < cl);
+    return ((uint64_t)nh << 32) | nl;
 }
 // torus word as signed 64-bit -> f64 with a single rounding
 __device__ __forceinline__ double torus_to_f64(uint64_t x)

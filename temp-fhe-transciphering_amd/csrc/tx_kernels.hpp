@@ -172,7 +172,7 @@ __device__ __forceinline__ void inv_add(cplx (&F)[8], uint64_t (&p)[16], const W
 {
     fft_inv(F, w.tw, w.tile, w.lane);
 #pragma unroll
-    for (int m = 0; m < 8; m++) { p[m] += f64_to_torus(F[m].x); p[m + 8] += f64_to_torus(F[m].y); }
+    for (int m = 0; m < 8; m++) { p[m] = torus_add_f64(p[m], F[m].x); p[m + 8] = torus_add_f64(p[m + 8], F[m].y); }
 }
 // the three accumulators of a GLWE together
 __device__ __forceinline__ void inv_add3(cplx (&F)[KP][8], uint64_t (&p)[KP][16], const WaveCtx &w)
@@ -181,7 +181,7 @@ __device__ __forceinline__ void inv_add3(cplx (&F)[KP][8], uint64_t (&p)[KP][16]
 #pragma unroll
     for (int c = 0; c < KP; c++)
 #pragma unroll
-        for (int m = 0; m < 8; m++) { p[c][m] += f64_to_torus(F[c][m].x); p[c][m + 8] += f64_to_torus(F[c][m].y); }
+        for (int m = 0; m < 8; m++) { p[c][m] = torus_add_f64(p[c][m], F[c][m].x); p[c][m + 8] = torus_add_f64(p[c][m + 8], F[c][m].y); }
 }
 
 template <int NCOL>
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             issue_fence();
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                a[lane + 64 * m] = cur[m] + f64_to_torus(F[c][m].x);
-                a[lane + 64 * (m + 8)] = cur[m + 8] + f64_to_torus(F[c][m].y);
+                a[lane + 64 * m] = torus_add_f64(cur[m], F[c][m].x);
+                a[lane + 64 * (m + 8)] = torus_add_f64(cur[m + 8], F[c][m].y);
             }
         }
     }
