@@ -192,6 +192,17 @@ extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
     return 0;
 }
 
+#ifdef TXD_STAMPS
+// diagnostic builds only: per-phase cycle sums of one wave of the last k_blind_rotate launch (tools/br_only.py)
+extern "C" int tx_debug_stamps(tx_ctx *c, unsigned long long *out16)
+{
+    if (!c || !out16) return fail("tx_debug_stamps: null");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(txd::txd_stamps), 16 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+
 // ---- key loading (SRV_AES:640-687) ----
 static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst, int mode)
 {

@@ -151,14 +151,28 @@ __device__ __forceinline__ void fft_inv(cplx (&v)[8], const cplx *tw, cplx *tile
 }
 
 
+// diagnostic only (-DTXD_STAMPS): cycle stamps inside a transform; st == nullptr compiles to nothing
+struct FftStamp { unsigned long long acc[4]; unsigned long long t; };
+__device__ __forceinline__ void fft_stamp(FftStamp *st, int k)
+{
+    if (st) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long n = __builtin_amdgcn_s_memtime();
+        st->acc[k] += n - st->t;
+        st->t = n;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // P polynomials transformed together: the twiddles of a pass are loaded once (batched, so the
 // LDS reads are all in flight before the first use) and the P tile round trips are issued back to
 // back on the same tile -- the LDS unit executes one wave's DS instructions in order, so poly p+1's
 // tile writes cannot overtake poly p's tile reads -- which lets butterflies of one polynomial
 // cover the LDS latency of the next.  Arithmetic per polynomial is identical to fft_fwd/fft_inv.
 template <int P>
-__device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)
+__device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane, FftStamp *st = nullptr)
 {
+    if (st) st->t = __builtin_amdgcn_s_memtime();
     // software pipeline over the P polynomials: polynomial p's tile round trip is in flight while
     // polynomial p+1's butterflies issue; the waits land at the next pass's first use of v[p].
     {
@@ -171,6 +185,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
 #pragma unroll
             for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], w[m]);
     }
+    fft_stamp(st, 0);
     {
         cplx w[7];
 #pragma unroll
@@ -184,6 +199,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
             xchg_hi(v[p], tile, lane);
         }
     }
+    fft_stamp(st, 1);
     {
         cplx w[7];
 #pragma unroll
@@ -197,8 +213,10 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
             xchg_lo(v[p], tile, lane);
         }
     }
+    fft_stamp(st, 2);
 #pragma unroll
     for (int p = 0; p < P; p++) dft8<+1>(v[p]);
+    fft_stamp(st, 3);
 }
 template <int P>
 __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx *tile, int lane)

@@ -20,6 +20,20 @@ constexpr int CBS_B = 2, CBS_L = 7;
 constexpr int LOG_LUT = 3;
 constexpr int LOGN = 10;
 
+#ifdef TXD_STAMPS       // diagnostic build: s_memtime per phase of k_blind_rotate, summed over the steps of one wave
+__device__ unsigned long long txd_stamps[16];                   // read back by tx_debug_stamps(); no output depends on it
+#define TXD_STAMP_DECL() unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(); FftStamp fst = {{0, 0, 0, 0}, 0}
+#define TXD_FST (&fst)
+#define TXD_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
+                          st_acc[k] += st_n - st_t; st_t = st_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TXD_STAMP_FLUSH(steps) do { if (blockIdx.x == 64 && threadIdx.x == 0) { for (int q = 0; q < 6; q++) txd_stamps[q] = st_acc[q]; \
+                                    txd_stamps[6] = (unsigned long long)(steps); for (int q = 0; q < 4; q++) txd_stamps[8 + q] = fst.acc[q]; } } while (0)
+#else
+#define TXD_STAMP_DECL() do {} while (0)
+#define TXD_FST nullptr
+#define TXD_STAMP(k) do {} while (0)
+#define TXD_STAMP_FLUSH(steps) do {} while (0)
+#endif
 #ifdef TXD_PHASE_MARK   // diagnostic build: phase comments in the ISA, counted by tools/isa_phases.py
 #define TXD_PHASE(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; TXPHASE " #k ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t thr = 0x400000u - (uint32_t)(lane & 1);
     cplx g[8];
     load_key8(g, bsk_f, lane);                              // key polynomial (step 0, row 0, col 0)
+    TXD_STAMP_DECL();
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         // a mask element equal to 0 (skipped at pbs.rs:111) rotates by 0: ct1 = 0 and the step adds 0
@@ -443,8 +458,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         TXD_PHASE(1);
-        fft_fwd_n<KP>(d, w.tw, w.tile, lane);
+        TXD_STAMP(0);
+        fft_fwd_n<KP>(d, w.tw, w.tile, lane, TXD_FST);
         TXD_PHASE(2);
+        TXD_STAMP(1);
         const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
         const int inext = (i + 1 < n) ? i + 1 : i;
         cplx F[KP][8];
@@ -463,8 +480,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 8; r++) g[r] = gn[r];
             }
         TXD_PHASE(3);
+        TXD_STAMP(2);
         fft_inv_n<KP>(F, w.tw, w.tile, lane);
         TXD_PHASE(4);
+        TXD_STAMP(3);
         wave_lds_fence();
 #pragma unroll
         for (int c = 0; c < KP; c++) {
@@ -479,7 +498,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a[lane + 64 * (m + 8)] = torus_add_f64(cur[m + 8], F[c][m].y);
             }
         }
+        TXD_STAMP(4);
     }
+    TXD_STAMP_FLUSH(n);
     wave_lds_fence();
     uint64_t *o = acc_out + (size_t)w.unit * GL;
 #pragma unroll

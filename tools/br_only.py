@@ -19,6 +19,13 @@ lwe = rnd(count * (n + 1)).reshape(count, n + 1)
 for r in range(reps):
     eng.blind_rotate(lwe)
     print("blind_rotate", count, "units:", round(eng.timing()["ms_blind_rotate"], 3), "ms", flush=True)
+if hasattr(txhip.lib(), "tx_debug_stamps"):        # -DTXD_STAMPS build: cycles per phase and step of one wave
+    st = (C.c_ulonglong * 16)()
+    txhip.lib().tx_debug_stamps(C.c_void_p(eng.h), st)
+    names = ["rotate+decompose", "forward x3", "MAC", "inverse x3", "convert+update"]
+    steps = max(1, st[6])
+    print("stamps (cycles/step):", {n: round(st[i] / steps) for i, n in enumerate(names)}, "sum", round(sum(st[:5]) / steps))
+    print("inside forward x3:", {n: round(st[8 + i] / steps) for i, n in enumerate(["twist", "dft8+tw+xchg_hi", "dft8+tw+xchg_lo", "dft8"])})
 if len(sys.argv) > 4:
     acc = rnd(count // 8 * 3072).reshape(-1, 3, 1024)
     for r in range(reps):
