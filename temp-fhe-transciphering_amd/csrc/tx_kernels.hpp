@@ -530,22 +530,24 @@ constexpr int TRACE_KEYS_PASS = 2 * AUTO_L * KP;            // key polynomials p
 // traffic and for all but the youngest DMA loads.  A barrier before the first DMA (every wave has finished its
 // forward transforms) and one after the last read (before the inverse transforms) fence the tiles' two uses.
 struct KeyRing {
-    unsigned char *slot0;       // wave 0's tile; slot s = slot0 + s * TRACE_WAVE_BYTES
+    unsigned char *slot0;       // wave 0's tile; slot s = slot0 + s * slot_stride
     uint32_t slot0_addr;        // the same as an LDS byte address (for M0)
-    const cplx *auto_f;
-    size_t split_stride;
+    uint32_t slot_stride;       // bytes between the tiles of consecutive waves
     int wave, lane;
 };
 __device__ __forceinline__ cplx *ring_slot(const KeyRing &k, int s)
 {
-    return reinterpret_cast<cplx *>(k.slot0 + (size_t)s * TRACE_WAVE_BYTES);
+    return reinterpret_cast<cplx *>(k.slot0 + (size_t)s * k.slot_stride);
 }
-// key polynomial j of pass (idx, split): (q, level finest first, column)
-__device__ __forceinline__ const cplx *trace_key(const KeyRing &k, int idx, int split, int j)
-{
-    const int q = j / (AUTO_L * KP), i = (j / KP) % AUTO_L, c = j % KP;
-    return k.auto_f + (size_t)split * k.split_stride + ((((size_t)idx * 2 + q) * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * H;
-}
+// key polynomial j of a trace pass (idx, split): (q, level finest first, column)
+struct TraceKeyFn {
+    const cplx *auto_f; size_t split_stride; int idx, split;
+    __device__ __forceinline__ const cplx *operator()(int j) const
+    {
+        const int q = j / (AUTO_L * KP), i = (j / KP) % AUTO_L, c = j % KP;
+        return auto_f + (size_t)split * split_stride + ((((size_t)idx * 2 + q) * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * H;
+    }
+};
 // one LDS-DMA load: 64 lanes x 16 B from per-lane global addresses to LDS [m0, m0 + 1 KiB).  In asm so that hipcc
 // does not count it: with the builtin it drains every DMA in flight (vmcnt(0)) before each read of a ring slot.
 __device__ __forceinline__ void glds16(const cplx *src, uint32_t lds_addr)
@@ -560,7 +562,7 @@ __device__ __forceinline__ void glds16(const cplx *src, uint32_t lds_addr)
 __device__ __forceinline__ void ring_dma(const KeyRing &k, const cplx *poly, int slot)
 {
     const cplx *src = poly + k.wave * 128 + k.lane;
-    const uint32_t dst = k.slot0_addr + (uint32_t)slot * (uint32_t)TRACE_WAVE_BYTES + (uint32_t)k.wave * 2048u;   // wave-uniform
+    const uint32_t dst = k.slot0_addr + (uint32_t)slot * k.slot_stride + (uint32_t)k.wave * 2048u;   // wave-uniform
     glds16(src, dst);
     glds16(src + 64, dst + 1024u);
 }
@@ -575,8 +577,8 @@ __device__ __forceinline__ void ring_barrier()
 #endif
 }
 
-template <int J>
-__device__ __forceinline__ void ring_step(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_L][8], const KeyRing &k, int idx, int split)
+template <int J, typename KeyFn>
+__device__ __forceinline__ void ring_step(cplx (&F)[KP][8], cplx (&Dg)[TRACE_KEYS_PASS / KP][8], const KeyRing &k, const KeyFn &key)
 {
     constexpr int ahead = (TRACE_KEYS_PASS - 1 - J < 2) ? TRACE_KEYS_PASS - 1 - J : 2;     // polynomials issued after J
     ring_barrier<2 * ahead>();                              // polynomial J landed everywhere; slot (J-1)%4 free
@@ -584,23 +586,24 @@ __device__ __forceinline__ void ring_step(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_
     const cplx *sl = ring_slot(k, J % 4);
 #pragma unroll
     for (int r = 0; r < 8; r++) g[r] = sl[r * 64 + k.lane];
-    if (J + 3 < TRACE_KEYS_PASS) ring_dma(k, trace_key(k, idx, split, J + 3), (J + 3) % 4);
+    if (J + 3 < TRACE_KEYS_PASS) ring_dma(k, key(J + 3), (J + 3) % 4);
     fmac8r(F[J % KP], Dg[J / KP], g);
 }
-// one pass over a key split: F[c] = sum over the six digit transforms of D * key, in the oracle's order
-__device__ __forceinline__ void ring_pass(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_L][8], const KeyRing &k, int idx, int split)
+// one pass over 18 shared key polynomials: F[c] += D[j / 3] * key(j), j = 0..17 (c = j % 3), in the oracle's order
+template <typename KeyFn>
+__device__ __forceinline__ void ring_pass(cplx (&F)[KP][8], cplx (&Dg)[TRACE_KEYS_PASS / KP][8], const KeyRing &k, const KeyFn &key)
 {
     static_assert(TRACE_KEYS_PASS == 18, "unrolled for 18 key polynomials per pass");
     ring_barrier<0>();                                      // every wave is done with its tile
-    ring_dma(k, trace_key(k, idx, split, 0), 0);
-    ring_dma(k, trace_key(k, idx, split, 1), 1);
-    ring_dma(k, trace_key(k, idx, split, 2), 2);
-    ring_step<0>(F, Dg, k, idx, split);   ring_step<1>(F, Dg, k, idx, split);   ring_step<2>(F, Dg, k, idx, split);
-    ring_step<3>(F, Dg, k, idx, split);   ring_step<4>(F, Dg, k, idx, split);   ring_step<5>(F, Dg, k, idx, split);
-    ring_step<6>(F, Dg, k, idx, split);   ring_step<7>(F, Dg, k, idx, split);   ring_step<8>(F, Dg, k, idx, split);
-    ring_step<9>(F, Dg, k, idx, split);   ring_step<10>(F, Dg, k, idx, split);  ring_step<11>(F, Dg, k, idx, split);
-    ring_step<12>(F, Dg, k, idx, split);  ring_step<13>(F, Dg, k, idx, split);  ring_step<14>(F, Dg, k, idx, split);
-    ring_step<15>(F, Dg, k, idx, split);  ring_step<16>(F, Dg, k, idx, split);  ring_step<17>(F, Dg, k, idx, split);
+    ring_dma(k, key(0), 0);
+    ring_dma(k, key(1), 1);
+    ring_dma(k, key(2), 2);
+    ring_step<0>(F, Dg, k, key);   ring_step<1>(F, Dg, k, key);   ring_step<2>(F, Dg, k, key);
+    ring_step<3>(F, Dg, k, key);   ring_step<4>(F, Dg, k, key);   ring_step<5>(F, Dg, k, key);
+    ring_step<6>(F, Dg, k, key);   ring_step<7>(F, Dg, k, key);   ring_step<8>(F, Dg, k, key);
+    ring_step<9>(F, Dg, k, key);   ring_step<10>(F, Dg, k, key);  ring_step<11>(F, Dg, k, key);
+    ring_step<12>(F, Dg, k, key);  ring_step<13>(F, Dg, k, key);  ring_step<14>(F, Dg, k, key);
+    ring_step<15>(F, Dg, k, key);  ring_step<16>(F, Dg, k, key);  ring_step<17>(F, Dg, k, key);
     ring_barrier<0>();                                      // every wave has read the last slot: tiles free again
 }
 
@@ -610,7 +613,7 @@ __device__ __forceinline__ void ring_pass(cplx (&F)[KP][8], cplx (&Dg)[2 * AUTO_
 // polynomials are transformed ONCE; they stay live (the register allocator parks them in the accumulation
 // registers, idle at one wave per SIMD) across the two passes over the split key (low 41 bits, high 23 bits);
 // each pass = 18 key polynomials from the shared ring, three inverse transforms and a read-modify-write of g.
-__device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, const WaveCtx &w)
+__device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, const cplx *auto_f, size_t split_stride, const WaveCtx &w)
 {
     typedef Decomp<AUTO_B, AUTO_L> D;
     constexpr int NP = 2 * AUTO_L;                 // digit polynomials per step
@@ -668,7 +671,7 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
         for (int s = 0; s < 2; s++) {
             cplx F[KP][8];
             zero_f(F);
-            ring_pass(F, Dg, ring, idx, s);
+            ring_pass(F, Dg, ring, TraceKeyFn{auto_f, split_stride, idx, s});
             fft_inv_n<KP>(F, w.tw, w.tile, lane);
             const int sh = s ? AUTO_SPLIT : 0;
             wave_lds_fence();
@@ -690,13 +693,12 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
     wave_lds_fence();
 }
 
-__device__ __forceinline__ KeyRing ring_setup(unsigned char *lds, const cplx *auto_f, size_t split_stride)
+__device__ __forceinline__ KeyRing ring_setup(unsigned char *lds, size_t wave_bytes)
 {
     KeyRing k;
     k.slot0 = lds + TW_ROWS * 64 * sizeof(cplx);
     k.slot0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)k.slot0);
-    k.auto_f = auto_f;
-    k.split_stride = split_stride;
+    k.slot_stride = (uint32_t)wave_bytes;
     k.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     k.lane = (int)(threadIdx.x & 63);
     return k;
@@ -729,8 +731,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing older than the ring's DMA on the VM counter
-    const KeyRing ring = ring_setup(lds, auto_f, split_stride);
-    trace_lds(gl, ring, w);
+    const KeyRing ring = ring_setup(lds, TRACE_WAVE_BYTES);
+    trace_lds(gl, ring, auto_f, split_stride, w);
     if (!active) return;
     uint64_t *o = glev + (size_t)w.unit * GL;
 #pragma unroll
@@ -754,8 +756,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int m = 0; m < 16; m++) gl[q * N + w.lane + 64 * m] = p[q * N + w.lane + 64 * m];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const KeyRing ring = ring_setup(lds, auto_f, split_stride);
-    trace_lds(gl, ring, w);
+    const KeyRing ring = ring_setup(lds, TRACE_WAVE_BYTES);
+    trace_lds(gl, ring, auto_f, split_stride, w);
     if (!active) return;
 #pragma unroll
     for (int q = 0; q < KP; q++)
@@ -783,36 +785,77 @@ __device__ __forceinline__ void store_fourier_scaled3(const uint64_t (&p)[KP][16
         for (int r = 0; r < 8; r++) o[(size_t)c * H + r * 64 + w.lane] = make_double2(v[c][r].x * 0x1p-9, v[c][r].y * 0x1p-9);
 }
 
+// key polynomial j of the scheme-switch pass for mask row `sel`: (GLev polynomial r, level finest first, column)
+struct SsKeyFn {
+    const cplx *ss_f; int sel;
+    __device__ __forceinline__ const cplx *operator()(int j) const
+    {
+        const int r = j / (SS_L * KP), i = (j / KP) % SS_L, c = j % KP;
+        return ss_f + ((((size_t)sel * SS_L + (SS_L - 1 - i)) * KP + r) * KP + c) * H;
+    }
+};
+
+// The six digit polynomials of the GLev element (3 polynomials x 2 levels) are transformed ONCE and serve both
+// mask rows; the scheme-switching key is the same for every unit, so each pass takes its 18 key polynomials from
+// the workgroup's shared ring (see the trace kernel).  Same products in the same order as extprod_row.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
                                                        const cplx *ss_f, const cplx *tw_g)
 {
+    static_assert(SS_L * KP * KP == TRACE_KEYS_PASS && SS_L == 2, "ring pass shape");
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds);
-    if (w.unit >= units) return;
+    const bool active = w.unit < units;            // idle waves of the last workgroup shadow the last unit:
+    if (!active) w.unit = units - 1;               // every wave takes part in the ring's barriers
     const uint64_t *gp = glev + (size_t)w.unit * GL;
     cplx *o = ggsw_f + (size_t)w.unit * KP * KP * H;
-    // the GLev element is re-read from global memory (L2) where needed instead of being held in
-    // 96 registers for the whole kernel
+    typedef Decomp<SS_B, SS_L> D;
+    cplx Dg[SS_L * KP][8];                         // [r * 2 + i], i = 0 the finest level
+#pragma unroll
+    for (int half = 0; half < 2; half++) {         // two groups of three digit polynomials, transformed together
+        cplx d[3][8];
+#pragma unroll
+        for (int r = 0; r < KP; r++) {
+            if ((r * SS_L) / 3 > half || (r * SS_L + SS_L - 1) / 3 < half) continue;
+            uint64_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = gp[r * N + w.lane + 64 * m];
+            typename D::state_t st[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) st[m] = D::init(x[m]);
+#pragma unroll
+            for (int i = 0; i < SS_L; i++) {
+                const typename D::state_t tie = (i == SS_L - 1) ? D::tie_mask(w.lane) : (typename D::state_t)0;
+                const int pidx = r * SS_L + i;
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const double re = (double)D::next(st[m], tie), im = (double)D::next(st[m + 8], tie);
+                    if (pidx / 3 == half) d[pidx % 3][m] = make_double2(re, im);
+                }
+            }
+        }
+        fft_fwd_n<3>(d, w.tw, w.tile, w.lane);
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int m = 0; m < 8; m++) Dg[half * 3 + q][m] = d[q][m];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing older than the ring's DMA on the VM counter
+    const KeyRing ring = ring_setup(lds, SCRATCH_CPLX * sizeof(cplx));
 #pragma unroll 1
     for (int i = 0; i < 2; i++) {
         cplx F[KP][8];
         zero_f(F);
-#pragma unroll 1
-        for (int r = 0; r < KP; r++) {
-            uint64_t lo[8], hi[8];
-#pragma unroll
-            for (int m = 0; m < 8; m++) { lo[m] = gp[r * N + w.lane + 64 * m]; hi[m] = gp[r * N + w.lane + 64 * m + 512]; }
-            const cplx *key = ss_f + (((size_t)i * SS_L) * KP + r) * KP * H;
-            extprod_row<SS_B, SS_L, KP>(F, lo, hi, key, (size_t)KP * KP * H, H, w);
-        }
+        ring_pass(F, Dg, ring, SsKeyFn{ss_f, i});
         uint64_t rows[KP][16];
 #pragma unroll
         for (int c = 0; c < KP; c++)
 #pragma unroll
             for (int m = 0; m < 16; m++) rows[c][m] = 0;
         inv_add3(F, rows, w);
-        store_fourier_scaled3(rows, o + (size_t)i * KP * H, w);
+        if (active) store_fourier_scaled3(rows, o + (size_t)i * KP * H, w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the stores above are off the VM counter before the next pass
     }
+    if (!active) return;
     {
         uint64_t in[KP][16];
 #pragma unroll
