@@ -90,6 +90,48 @@ __device__ __forceinline__ void wave_lds_fence()
 // 8x8 transposes through the per-wave tile (pitch 65 complex => conflict-free b128 stores/loads).
 //   xchg_hi: element (lane = 8a+b, reg r)  ->  (lane = 8r+b, reg a)
 //   xchg_lo: element (lane = 8g+b, reg r)  ->  (lane = 8g+r, reg b)
+#ifdef TXD_XCHG_HI_VALU
+// xchg_hi without LDS: the 3-bit register index is swapped with lane bits 5, 4, 3 one bit at a time --
+// v_permlane32_swap (bit 5), v_permlane16_swap (bit 4), and a pair of bank-masked row_ror:8 DPP moves (bit 3).
+// The LDS store path (79 B/clk per CU, shared by the four waves) is the scarcer resource than VALU issue.
+__device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *, int)
+{
+#ifdef TXD_ABL_NOXCHG
+    return;
+#endif
+    uint32_t d[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint64_t a = (uint64_t)__double_as_longlong(v[r].x), b = (uint64_t)__double_as_longlong(v[r].y);
+        d[r][0] = (uint32_t)a; d[r][1] = (uint32_t)(a >> 32); d[r][2] = (uint32_t)b; d[r][3] = (uint32_t)(b >> 32);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {                       // register bit 2 <-> lane bit 5
+            auto t = __builtin_amdgcn_permlane32_swap(d[r][k], d[r + 4][k], false, false);
+            d[r][k] = t[0]; d[r + 4][k] = t[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                       // register bit 1 <-> lane bit 4
+            const int r = (q & 1) | ((q & 2) << 1);
+            auto t = __builtin_amdgcn_permlane16_swap(d[r][k], d[r + 2][k], false, false);
+            d[r][k] = t[0]; d[r + 2][k] = t[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {                    // register bit 0 <-> lane bit 3
+            const uint32_t a = d[r][k], b = d[r + 1][k];
+            d[r + 1][k] = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);    // lanes 0-7 of a row <- a[lane + 8]
+            d[r][k] = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);        // lanes 8-15 <- b[lane - 8]
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        v[r] = make_double2(__longlong_as_double((long long)(((uint64_t)d[r][1] << 32) | d[r][0])),
+                            __longlong_as_double((long long)(((uint64_t)d[r][3] << 32) | d[r][2])));
+    issue_fence();
+}
+#else
 __device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
 {
 #ifdef TXD_ABL_NOXCHG
@@ -105,6 +147,7 @@ __device__ __forceinline__ void xchg_hi(cplx (&v)[8], cplx *tile, int lane)
     for (int r = 0; r < 8; r++) v[r] = tile[r * XPITCH + lane];
     issue_fence();
 }
+#endif
 __device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
 {
 #ifdef TXD_ABL_NOXCHG
