@@ -83,3 +83,20 @@ def test_client_aes_and_bit_packing():
     assert txclient.aes_ecb_encrypt(key, bytes.fromhex("00112233445566778899aabbccddeeff")).hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"
     bits = np.array([1] + [0] * 15 + [0] * 15 + [1], np.uint8)
     assert txclient.bits_to_u16(bits).tolist() == [0x8000, 1]
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the drop-in boundary is a C ABI: the header must compile as strict C99 (no C++ or torch types) and link
+    against the shared library from a C translation unit"""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "tfhe_mi355x.h"\n'
+                   'int main(void) { tx_params p; tx_params_aes_tight(&p); return !(p.N == 1024 && p.k == 2 && tx_last_error() != 0); }\n')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "temp-fhe-transciphering_amd")
+    exe = tmp_path / "abi_c"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+                        "-L", libdir, "-ltfhe_mi355x", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)       # no GPU call: parameter table only
+    assert r.returncode == 0, r.stdout + r.stderr
