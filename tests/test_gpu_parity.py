@@ -342,3 +342,21 @@ def test_sharded_runner_two_ranks_share_one_gpu():
     assert r.returncode == 0, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     assert _json.loads(line)["checks"] == {"aes": True, "max": True, "inner_product": True}
+
+
+def test_trace_and_scheme_switch_ring_stress(rig256):
+    """the workgroup-shared key ring (LDS-DMA + barriers) under a full chip: 300 random accumulators = 2100 trace
+    units (partial last workgroup: 2100 % 4 = 0, so a second call with 299 exercises the idle-wave path), every
+    output word identical to the oracle; then the scheme switch over all 2100 GLev elements"""
+    O, eng, octx = rig256.O, rig256.eng, rig256.octx
+    rng = np.random.default_rng(77)
+    acc = rng.integers(0, 1 << 63, (300, 3, 1024), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (300, 3, 1024), dtype=np.uint64)
+    g_o = octx.extract_trace(acc)
+    for rep in range(3):                                   # repeated launches: a race would not repeat identically
+        assert np.array_equal(eng.extract_trace(acc), g_o)
+    assert np.array_equal(eng.extract_trace(acc[:299]), g_o[:299])
+    glev = g_o[:150]
+    f_o = octx.ggsw_to_fourier(octx.scheme_switch(glev))
+    for rep in range(2):
+        assert np.array_equal(eng.scheme_switch_fourier(glev), f_o)
+    assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
