@@ -55,9 +55,14 @@ void    tx_destroy(tx_ctx *c);
  *   auto_keys standard-domain GLWE key-switch keys for t = N/2^(i-1)+1, i = 1..log2 N:
  *             [log2 N][k][auto_level][K][N]  (auto_keys.bin :633-643 holds their Fourier form)
  *   ss_key    GgswCiphertextListOwned<u64>   [k][ss_level][K][K][N]          (ss_key.bin, :632)
- * levels are stored level 1 (coarsest) first, as tfhe-rs does. K = k + 1. */
-int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, const uint64_t *ksk,
-                      const uint64_t *auto_keys, const uint64_t *ss_key);
+ * levels are stored level 1 (coarsest) first, as tfhe-rs does. K = k + 1.
+ * Each buffer comes with its length in 64-bit words; a length that is not exactly the one the
+ * context's parameters imply (a truncated file, keys generated for another n) is rejected before
+ * anything is read, as the reference's bincode deserialisation into typed containers would. */
+int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t bsk_words, const uint64_t *ksk, size_t ksk_words,
+                      const uint64_t *auto_keys, size_t auto_words, const uint64_t *ss_key, size_t ss_words);
+/* the word counts tx_load_eval_keys expects for this context (in the order bsk, ksk, auto, ss) */
+int tx_eval_key_words(const tx_ctx *c, size_t out4[4]);
 
 /* `AllRdKeys` (submission/src/data_struct.rs:10-26; trans_key.bin, SRV_AES :635) as one blob:
  * [set 0..8][mult x9,x11,x13,x14][byte 16][acc 2][K][N] then round 0 [byte 16][acc 2][K][N];

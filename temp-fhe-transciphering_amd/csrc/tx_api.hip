@@ -5,6 +5,7 @@
 // tx_kernels.hpp.  There is no CPU fallback: every entry point fails if HIP does.
 #include "../../include/tfhe_mi355x.h"
 #include "tx_kernels.hpp"
+#include "tx_br2.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -35,6 +36,9 @@ struct tx_ctx {
     cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
     size_t auto_split_stride = 0;
     cplx *tw = nullptr, *tw256 = nullptr;
+    unsigned int *unit_counter = nullptr;   // work counter of the persistent blind rotation
+    int num_cus = 0;
+    int br_variant = 0;
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
     // workspace (grown on demand)
@@ -52,6 +56,7 @@ struct tx_ctx {
 
 extern "C" void tx_params_aes_tight(tx_params *p)
 {   // cbs_lib/src/aes_instances.rs:76-97
+    if (!p) return;
     p->n = 768; p->N = 1024; p->k = 2;
     p->pbs_base_log = 23; p->pbs_level = 1;
     p->ks_base_log = 4; p->ks_level = 3; p->ks_N = 256;
@@ -90,7 +95,7 @@ static int upload_tables(tx_ctx *c)
 
 extern "C" tx_ctx *tx_create(const tx_params *p, int device)
 {
-    tx_params ref; tx_params_aes_tight(&ref);
+    if (!p) { fail("tx_create: null parameter set"); return nullptr; }
     if (p->N != (uint32_t)N || p->k != 2 || p->pbs_base_log != PBS_B || p->pbs_level != PBS_L ||
         p->ks_base_log != KS_B || p->ks_level != KS_L || p->ks_N != KS_N || p->auto_base_log != AUTO_B ||
         p->auto_level != AUTO_L || p->auto_split != AUTO_SPLIT || p->ss_base_log != SS_B || p->ss_level != SS_L ||
@@ -116,6 +121,15 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
                             (int)LDS_BYTES_BR) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the trace kernels"); delete c; return nullptr;
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipMalloc(&c->unit_counter, 64) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR2) != hipSuccess) {
+        fail("tx_create: cannot set up the persistent blind rotation"); delete c; return nullptr;
+    }
+    c->num_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("TX_BR_VARIANT")) c->br_variant = atoi(e);
     return c;
 }
 
@@ -134,7 +148,7 @@ extern "C" void tx_destroy(tx_ctx *c)
     hipStreamSynchronize(c->stream);
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
-    hipFree(c->tw); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
+    hipFree(c->tw); hipFree(c->unit_counter); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     hipStreamDestroy(c->stream);
     delete c;
@@ -222,14 +236,26 @@ static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst
     return 0;
 }
 
-extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, const uint64_t *ksk, const uint64_t *auto_keys,
-                                 const uint64_t *ss_key)
+extern "C" int tx_eval_key_words(const tx_ctx *c, size_t out4[4])
+{
+    if (!c || !out4) return fail("tx_eval_key_words: null argument");
+    out4[0] = bsk_words(c->p); out4[1] = ksk_words(c->p); out4[2] = auto_words(); out4[3] = ss_words();
+    return 0;
+}
+
+extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t n_bsk, const uint64_t *ksk, size_t n_ksk,
+                                 const uint64_t *auto_keys, size_t n_auto, const uint64_t *ss_key, size_t n_ss)
 {
     if (!c || !bsk || !ksk || !auto_keys || !ss_key) return fail("tx_load_eval_keys: null argument");
+    const size_t nb = bsk_words(c->p), nk = ksk_words(c->p), na = auto_words(), ns = ss_words();
+    if (n_bsk != nb || n_ksk != nk || n_auto != na || n_ss != ns)       // nothing is read from a buffer of the wrong length
+        return fail("tx_load_eval_keys: key length mismatch (bsk " + std::to_string(n_bsk) + "/" + std::to_string(nb) +
+                    ", ksk " + std::to_string(n_ksk) + "/" + std::to_string(nk) + ", auto " + std::to_string(n_auto) + "/" +
+                    std::to_string(na) + ", ss " + std::to_string(n_ss) + "/" + std::to_string(ns) +
+                    " words given/expected for n = " + std::to_string(c->p.n) + ")");
     HIP_OK(hipSetDevice(c->device));
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
     c->bsk_f = c->ksk_f = c->auto_f = c->ss_f = nullptr; c->have_keys = false;
-    const size_t nb = bsk_words(c->p), nk = ksk_words(c->p), na = auto_words(), ns = ss_words();
     HIP_OK(hipMalloc(&c->bsk_f, nb * 8));
     HIP_OK(hipMalloc(&c->ksk_f, nk * 8));
     HIP_OK(hipMalloc(&c->auto_f, na * 8 * 2));
@@ -297,6 +323,12 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
+    if (c->br_variant == 2) {
+        hipMemsetAsync(c->unit_counter, 0, 4, c->stream);
+        const size_t wgs = std::min<size_t>((count + BR2_WAVES - 1) / BR2_WAVES, (size_t)c->num_cus);
+        hipLaunchKernelGGL(k_blind_rotate2, dim3(wgs), dim3(512), LDS_BYTES_BR2, c->stream, in, acc, (int)count,
+                           (int)c->p.n, c->bsk_f, c->tw, c->unit_counter);
+    } else
     hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
                        (int)c->p.n, c->bsk_f, c->tw);
     ev_end(c);
@@ -542,30 +574,29 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
         return fail("hipMalloc failed");
     HIP_OK(hipMemcpyAsync(cur.p, lwe_bits, cnt * v16 * 8, hipMemcpyHostToDevice, c->stream));
     uint64_t *pc = (uint64_t *)cur.p, *pn = (uint64_t *)nxt.p;
-    while (cnt > 1) {
-        const size_t pairs = cnt / 2, units = pairs * 16, nx = pairs + (cnt & 1);
-        run_cbs(c, pc, 2 * pairs * 16, c->ggsw_f);
-        // operands as GLWEs: A[q][t] = value 2q bit t, B = value 2q+1 bit t (strided gather by pairs)
-        for (size_t q = 0; q < pairs; q++) {
-            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(16 * GL)), dim3(256), 0, c->stream, pc + (2 * q) * v16,
-                               (uint64_t *)A.p + q * 16 * GL, 16);
-            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(16 * GL)), dim3(256), 0, c->stream, pc + (2 * q + 1) * v16,
-                               (uint64_t *)B.p + q * 16 * GL, 16);
-        }
-        HIP_OK(hipMemcpyAsync(E.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));   // e = a (SURVEY 3.2 fix)
-        // selector tables: for scan step i (bit index i, MSB-first storage), unit (q,t)
-        std::vector<int> ha(units * 16), hb(units * 16);
+    {   // selector tables, built ONCE for the first (largest) level: for scan step i (bit index i, MSB-first
+        // storage) unit (q, t) selects GGSW (2q) * 16 + i (operand a) or (2q + 1) * 16 + i (operand b).  A later
+        // level with fewer pairs uses the first `units` entries of each step's row: rows are maxu entries apart.
+        std::vector<int> ha(maxu * 16), hb(maxu * 16);
         for (int i = 0; i < 16; i++)
-            for (size_t q = 0; q < pairs; q++)
+            for (size_t q = 0; q < cnt / 2; q++)
                 for (int t = 0; t < 16; t++) {
-                    ha[(size_t)i * units + q * 16 + t] = (int)((2 * q) * 16 + i);
-                    hb[(size_t)i * units + q * 16 + t] = (int)((2 * q + 1) * 16 + i);
+                    ha[(size_t)i * maxu + q * 16 + t] = (int)((2 * q) * 16 + i);
+                    hb[(size_t)i * maxu + q * 16 + t] = (int)((2 * q + 1) * 16 + i);
                 }
         HIP_OK(hipMemcpyAsync(sela.p, ha.data(), ha.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(selb.p, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));         // the host vectors go out of scope
+    }
+    while (cnt > 1) {
+        const size_t pairs = cnt / 2, units = pairs * 16, nx = pairs + (cnt & 1);
+        run_cbs(c, pc, 2 * pairs * 16, c->ggsw_f);
+        // operands as GLWEs: A[q][t] = value 2q bit t, B = value 2q+1 bit t: one strided launch each
+        hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, pc, (uint64_t *)A.p, (int)units, 2, 0);
+        hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, pc, (uint64_t *)B.p, (int)units, 2, 1);
+        HIP_OK(hipMemcpyAsync(E.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));   // e = a (SURVEY 3.2 fix)
         for (int i = 15; i >= 0; i--) {                 // .rev(): least significant bit first
-            const int *sa = (const int *)sela.p + (size_t)i * units, *sb = (const int *)selb.p + (size_t)i * units;
+            const int *sa = (const int *)sela.p + (size_t)i * maxu, *sb = (const int *)selb.p + (size_t)i * maxu;
             ev_begin(c, F_LUT);
             HIP_OK(hipMemcpyAsync(M0.p, E.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
             hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M0.p,
@@ -581,8 +612,7 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
         hipLaunchKernelGGL(k_extract0, dim3(ew_grid(units * BIG)), dim3(256), 0, c->stream, (const uint64_t *)E.p, pn,
                            (int)units);
         if (cnt & 1) HIP_OK(hipMemcpyAsync(pn + pairs * v16, pc + (cnt - 1) * v16, v16 * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipGetLastError());                      // levels are ordered by the stream: no host synchronisation
         std::swap(pc, pn);
         cnt = nx;
     }

@@ -26,7 +26,10 @@ __device__ unsigned long long txd_stamps[16];                   // read back by 
 #define TXD_FST (&fst)
 #define TXD_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
                           st_acc[k] += st_n - st_t; st_t = st_n; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define TXD_STAMP_FLUSH(steps) do { if (blockIdx.x == 64 && threadIdx.x == 0) { for (int q = 0; q < 6; q++) txd_stamps[q] = st_acc[q]; \
+#ifndef TXD_STAMP_THREAD
+#define TXD_STAMP_THREAD 0
+#endif
+#define TXD_STAMP_FLUSH(steps) do { if (blockIdx.x == 64 && threadIdx.x == TXD_STAMP_THREAD) { for (int q = 0; q < 6; q++) txd_stamps[q] = st_acc[q]; \
                                     txd_stamps[6] = (unsigned long long)(steps); for (int q = 0; q < 4; q++) txd_stamps[8 + q] = fst.acc[q]; } } while (0)
 #else
 #define TXD_STAMP_DECL() do {} while (0)
@@ -529,6 +532,15 @@ constexpr int TRACE_KEYS_PASS = 2 * AUTO_L * KP;            // key polynomials p
 // (8 x ds_read_b128).  One s_barrier per key polynomial keeps the waves in step; it waits for this wave's LDS
 // traffic and for all but the youngest DMA loads.  A barrier before the first DMA (every wave has finished its
 // forward transforms) and one after the last read (before the inverse transforms) fence the tiles' two uses.
+//
+// INVARIANT (hand-counted waits): ring_step waits with s_waitcnt vmcnt(2 * ahead), i.e. it assumes that the two
+// LDS-DMA loads per key polynomial are the ONLY vector-memory operations this wave has in flight between the first
+// and the last ring_barrier of a pass.  No global load or store (and no scratch spill) may be added inside
+// ring_pass / ring_step or between the ring_barrier calls of trace_lds and k_scheme_switch: it would shift the
+// count and turn a slot read into a read-before-arrival race that only the bit-parity tests detect.  Callers
+// drain the counter first (s_waitcnt vmcnt(0) before ring_setup, and after the stores of a scheme-switch pass).
+// M0 carries the LDS destination, which on gfx950 may lie above 64 KiB (160 KiB of LDS).  The -m gpu stress test
+// test_trace_and_scheme_switch_ring_stress (tests/test_gpu_parity.py) drives the ring with a partially idle last workgroup after any change.
 struct KeyRing {
     unsigned char *slot0;       // wave 0's tile; slot s = slot0 + s * slot_stride
     uint32_t slot0_addr;        // the same as an LDS byte address (for M0)
@@ -613,6 +625,7 @@ __device__ __forceinline__ void ring_pass(cplx (&F)[KP][8], cplx (&Dg)[TRACE_KEY
 // polynomials are transformed ONCE; they stay live (the register allocator parks them in the accumulation
 // registers, idle at one wave per SIMD) across the two passes over the split key (low 41 bits, high 23 bits);
 // each pass = 18 key polynomials from the shared ring, three inverse transforms and a read-modify-write of g.
+// Ring invariant (see KeyRing): nothing in this function touches global memory except ring_dma.
 __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, const cplx *auto_f, size_t split_stride, const WaveCtx &w)
 {
     typedef Decomp<AUTO_B, AUTO_L> D;
@@ -841,6 +854,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing older than the ring's DMA on the VM counter
     const KeyRing ring = ring_setup(lds, SCRATCH_CPLX * sizeof(cplx));
+    // Ring invariant (see KeyRing): inside ring_pass the ring's DMA loads are the only vector-memory operations in
+    // flight; the stores of store_fourier_scaled3 are drained (vmcnt(0)) before the next pass starts.
 #pragma unroll 1
     for (int i = 0; i < 2; i++) {
         cplx F[KP][8];
@@ -1050,13 +1065,15 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *st, uint64_t *
     }
 }
 
-// LWE (big) -> GLWE with the message in the constant coefficient (glwe_conv.rs:12-44), batched
-__global__ __launch_bounds__(256) void k_lwe_to_glwe(const uint64_t *lwe, uint64_t *glwe, int count)
+// LWE (big) -> GLWE with the message in the constant coefficient (glwe_conv.rs:12-44), batched.
+// Output unit u reads input LWE (u / 16 * gstride + goff) * 16 + u % 16: with (gstride, goff) = (2, 0) / (2, 1)
+// one launch gathers the even / odd 16-bit values of a tournament level (1, 0 = contiguous).
+__global__ __launch_bounds__(256) void k_lwe_to_glwe(const uint64_t *lwe, uint64_t *glwe, int count, int gstride, int goff)
 {
     const size_t total = (size_t)count * GL;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         size_t u = e / GL; int w = (int)(e % GL), q = w / N, j = w % N;
-        const uint64_t *a = lwe + u * BIG;
+        const uint64_t *a = lwe + (((u >> 4) * (size_t)gstride + (size_t)goff) * 16 + (u & 15)) * BIG;
         uint64_t v;
         if (q < 2) v = (j == 0) ? a[q * N] : (uint64_t)0 - a[q * N + N - j];
         else v = (j == 0) ? a[2 * N] : 0;

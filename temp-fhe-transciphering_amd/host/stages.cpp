@@ -47,6 +47,10 @@ std::vector<uint64_t> read_words(const std::string &path)
     if (!f) throw std::runtime_error("cannot read " + path);
     uint64_t hdr[2];
     if (fread(hdr, 8, 2, f) != 2 || hdr[0] != 0x0000003436555854ull) { fclose(f); throw std::runtime_error("bad header in " + path); }
+    struct stat sb;                                     // the header's word count must be what the file holds
+    if (fstat(fileno(f), &sb) != 0 || sb.st_size < 16 || (uint64_t)(sb.st_size - 16) / 8 != hdr[1] || (sb.st_size - 16) % 8 != 0) {
+        fclose(f); throw std::runtime_error("word count in the header of " + path + " does not match the file size");
+    }
     std::vector<uint64_t> v(hdr[1]);
     if (fread(v.data(), 8, v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short read " + path); }
     fclose(f);
@@ -84,8 +88,9 @@ int client_key_generation(int size)
     tx_params prm; tx_params_aes_tight(&prm);
     std::vector<uint64_t> lwe(prm.n), glwe((size_t)prm.k * prm.N), bsk(txc_bsk_words(&prm)), ksk(txc_ksk_words(&prm)),
         au(txc_auto_words(&prm)), ss(txc_ss_words(&prm));
-    if (txc_keygen(&prm, env_seed("TX_SEED"), lwe.data(), glwe.data(), bsk.data(), ksk.data(), au.data(), ss.data()))
-        throw std::runtime_error("key generation failed");
+    const int rc = txc_keygen(&prm, env_seed("TX_SEED"), lwe.data(), glwe.data(), bsk.data(), ksk.data(), au.data(), ss.data());
+    if (rc == TXC_ERR_ENTROPY) throw std::runtime_error("key generation failed: the OS returned no entropy");
+    if (rc) throw std::runtime_error("key generation failed");
     write_words(p.io + "/secret_keys/lwe_sk.bin", lwe);
     write_words(p.io + "/secret_keys/glwe_sk.bin", glwe);
     write_words(p.io + "/public_keys/bsk.bin", bsk);
@@ -103,8 +108,10 @@ int client_encode_encrypt(int size)
     std::vector<uint64_t> glwe = read_words(p.io + "/secret_keys/glwe_sk.bin");
     std::vector<uint64_t> luts(size == 0 ? txc_lut_words(&prm) : txc_ctr_lut_words(&prm));
     uint64_t seed = env_seed("TX_SEED");
-    if (size == 0) txc_make_round_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data());
-    else txc_make_ctr_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data());
+    const int rc = (size == 0) ? txc_make_round_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data())
+                               : txc_make_ctr_luts(&prm, seed ? seed + 1 : 0, key.data(), glwe.data(), luts.data());
+    if (rc == TXC_ERR_ENTROPY) throw std::runtime_error("transciphering-key encryption failed: the OS returned no entropy");
+    if (rc) throw std::runtime_error("transciphering-key encryption failed");
     write_words(p.io + "/ciphertexts_upload/trans_key.bin", luts);
     return 0;
 }
@@ -141,7 +148,10 @@ tx_ctx *server_context(const Paths &p, const tx_params &prm)
     if (!c) throw std::runtime_error(std::string("tx_create: ") + tx_last_error());
     std::vector<uint64_t> bsk = read_words(p.io + "/public_keys/bsk.bin"), ksk = read_words(p.io + "/public_keys/ksk.bin"),
         au = read_words(p.io + "/public_keys/auto_keys.bin"), ss = read_words(p.io + "/public_keys/ss_key.bin");
-    check(tx_load_eval_keys(c, bsk.data(), ksk.data(), au.data(), ss.data()), "tx_load_eval_keys");
+    if (bsk.size() != txc_bsk_words(&prm) || ksk.size() != txc_ksk_words(&prm) || au.size() != txc_auto_words(&prm) ||
+        ss.size() != txc_ss_words(&prm)) { tx_destroy(c); throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set"); }
+    check(tx_load_eval_keys(c, bsk.data(), bsk.size(), ksk.data(), ksk.size(), au.data(), au.size(), ss.data(), ss.size()),
+          "tx_load_eval_keys");
     return c;
 }
 int server_encrypted_aes_decryption(int size)

@@ -3,8 +3,10 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <sys/random.h>
 
 namespace {
 
@@ -15,15 +17,16 @@ struct ChaCha {
     int pos = 64;
     bool have_spare = false;
     double spare = 0;
+    bool ok = true;             // false: no entropy for an unseeded generator; every entry point then fails
     static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
     explicit ChaCha(uint64_t seed, uint64_t stream)
     {
         static const uint32_t sigma[4] = { 0x61707865, 0x3320646e, 0x79622d32, 0x6b206574 };
         uint8_t key[32] = { 0 };
         if (seed == 0) {
-            FILE *f = fopen("/dev/urandom", "rb");
-            if (!f || fread(key, 1, 32, f) != 32) memset(key, 0x5a, 32);
-            if (f) fclose(f);
+            // production path: 256 bits from the OS; no entropy is an ERROR (never a constant key:
+            // secret keys, masks and noise would all be predictable)
+            ok = os_entropy(key, sizeof key);
         } else {
             for (int i = 0; i < 8; i++) key[i] = (uint8_t)(seed >> (8 * i));
             for (int i = 8; i < 32; i++) key[i] = (uint8_t)(0xA5 ^ (i * 29));
@@ -32,6 +35,21 @@ struct ChaCha {
         for (int i = 0; i < 8; i++) memcpy(&st[4 + i], key + 4 * i, 4);
         st[12] = 0; st[13] = 0;
         st[14] = (uint32_t)stream; st[15] = (uint32_t)(stream >> 32);
+    }
+    static bool os_entropy(uint8_t *dst, size_t len)
+    {
+        if (getenv("TXC_TEST_NO_ENTROPY")) return false;           // test hook for the failure path only
+        size_t got = 0;
+        while (got < len) {
+            ssize_t r = getrandom(dst + got, len - got, 0);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got == len) return true;
+        FILE *f = fopen("/dev/urandom", "rb");                     // kernels without getrandom(2)
+        const bool rd = f && fread(dst, 1, len, f) == len;
+        if (f) fclose(f);
+        return rd;
     }
     void block()
     {
@@ -238,6 +256,7 @@ int txc_keygen(const tx_params *pp, uint64_t seed, uint64_t *lwe_sk, uint64_t *g
     const uint32_t N = p.N, k = p.k, K = k + 1, n = p.n;
     if (n % p.ks_N || (k * N) % p.ks_N) return -1;
     ChaCha secret(seed, 1), enc(seed, 2);
+    if (!secret.ok || !enc.ok) return TXC_ERR_ENTROPY;
     // cbs_lib/src/keygen.rs:208-217
     for (uint32_t i = 0; i < n; i++) lwe_sk[i] = secret.u64() & 1;
     for (uint32_t i = 0; i < k * N; i++) glwe_sk[i] = secret.u64() & 1;
@@ -285,9 +304,21 @@ int txc_keygen(const tx_params *pp, uint64_t seed, uint64_t *lwe_sk, uint64_t *g
 
 int txc_make_round_luts(const tx_params *pp, uint64_t seed, const uint8_t aes_key[16], const uint64_t *glwe_sk, uint64_t *luts)
 {
+    return txc_make_round_luts_ex(pp, seed, aes_key, glwe_sk, 0, luts);
+}
+
+int txc_make_round_luts_ex(const tx_params *pp, uint64_t seed, const uint8_t aes_key[16], const uint64_t *glwe_sk,
+                           unsigned flags, uint64_t *luts)
+{
     const tx_params &p = *pp;
     Aes aes(aes_key);
     ChaCha enc(seed, 3);
+    if (!enc.ok) return TXC_ERR_ENTROPY;
+    // The reference encrypts only the fused round-10/9 tables and ships rounds 8..0 as TRIVIAL (mask 0,
+    // noiseless) GLWEs (data_struct.rs:146-151, :258-263): the table bits are then readable by the server,
+    // any one round key falls out of them, and the AES-128 key schedule is invertible.  Here every table is a
+    // real GLWE encryption unless the caller asks for the reference's form explicitly.
+    const bool trivial = (flags & TXC_LUTS_REFERENCE_TRIVIAL) != 0;
     const size_t gl = (size_t)(p.k + 1) * p.N;
     static const uint8_t mults[4] = { 9, 11, 13, 14 };
     uint8_t base[256], tab[256];
@@ -301,11 +332,11 @@ int txc_make_round_luts(const tx_params *pp, uint64_t seed, const uint8_t aes_ke
                     for (int x = 0; x < 256; x++) base[x] = aes.inv[x] ^ aes.rk[9 - set][j];
                 }
                 for (int x = 0; x < 256; x++) tab[x] = Aes::mul(base[x], mults[m]);
-                emit_lut(p, enc, glwe_sk, set == 0, tab, luts + ((((size_t)set * 4 + m) * 16 + j) * 2) * gl);
+                emit_lut(p, enc, glwe_sk, set == 0 || !trivial, tab, luts + ((((size_t)set * 4 + m) * 16 + j) * 2) * gl);
             }
     for (int j = 0; j < 16; j++) {       // aes_manager.rs:422-432
         for (int x = 0; x < 256; x++) tab[x] = aes.inv[x] ^ aes.rk[0][j];
-        emit_lut(p, enc, glwe_sk, false, tab, luts + (((size_t)9 * 4 * 16 + j) * 2) * gl);
+        emit_lut(p, enc, glwe_sk, !trivial, tab, luts + (((size_t)9 * 4 * 16 + j) * 2) * gl);
     }
     return 0;
 }
@@ -315,6 +346,7 @@ int txc_make_ctr_luts(const tx_params *pp, uint64_t seed, const uint8_t aes_key[
     const tx_params &p = *pp;
     Aes aes(aes_key);
     ChaCha enc(seed, 4);
+    if (!enc.ok) return TXC_ERR_ENTROPY;
     const size_t gl = (size_t)(p.k + 1) * p.N;
     memset(luts, 0, sizeof(uint64_t) * txc_ctr_lut_words(pp));
     uint8_t tab[256];
@@ -327,7 +359,8 @@ int txc_make_ctr_luts(const tx_params *pp, uint64_t seed, const uint8_t aes_key[
                     const uint8_t s = aes.sbox[x ^ aes.rk[set][j]];
                     tab[x] = (set == 9) ? (uint8_t)(s ^ aes.rk[10][dst]) : Aes::mul(s, (uint8_t)(m + 1));
                 }
-                emit_lut(p, enc, glwe_sk, set == 0, tab, luts + ((((size_t)set * 3 + m) * 16 + j) * 2) * gl);
+                // every set is a real encryption: a trivial table would hand rk_set to the server in the clear
+                emit_lut(p, enc, glwe_sk, true, tab, luts + ((((size_t)set * 3 + m) * 16 + j) * 2) * gl);
             }
     return 0;
 }
@@ -349,6 +382,7 @@ int txc_encrypt_bits(const tx_params *p, uint64_t seed, const uint64_t *sk, cons
 {
     const size_t dim = (size_t)p->k * p->N;
     ChaCha enc(seed, 5);
+    if (!enc.ok) return TXC_ERR_ENTROPY;
     for (size_t c = 0; c < count; c++) {
         uint64_t *x = lwe + c * (dim + 1);
         uint64_t b = ((uint64_t)(bits[c] & 1) << 63) + enc.noise(p->glwe_std);

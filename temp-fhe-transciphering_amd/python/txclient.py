@@ -22,6 +22,21 @@ def _p64(a): return a.ctypes.data_as(u64p)
 def _p8(a): return a.ctypes.data_as(u8p)
 
 
+ERR_ENTROPY = -2                     # txclient.h TXC_ERR_ENTROPY
+LUTS_REFERENCE_TRIVIAL = 1           # txclient.h TXC_LUTS_REFERENCE_TRIVIAL
+
+
+class ClientError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc == ERR_ENTROPY:
+        raise ClientError(what + ": the OS returned no entropy for an unseeded generator")
+    if rc:
+        raise ClientError(what + " failed (%d)" % rc)
+
+
 class ClientKeys:
     """What client_key_generation writes: secret keys + the four evaluation keys (standard domain)."""
 
@@ -36,19 +51,23 @@ class ClientKeys:
         self.ss = np.zeros(L.txc_ss_words(C.byref(p)), np.uint64)
         rc = L.txc_keygen(C.byref(p), C.c_uint64(seed), _p64(self.lwe_sk), _p64(self.glwe_sk), _p64(self.bsk),
                           _p64(self.ksk), _p64(self.auto), _p64(self.ss))
-        if rc:
-            raise RuntimeError("txc_keygen failed")
+        _chk(rc, "txc_keygen")
 
-    def round_luts(self, aes_key, seed):
+    def round_luts(self, aes_key, seed, reference_trivial=False):
+        """every table GLWE-encrypted; reference_trivial=True gives the reference's form (rounds 8..0 as
+        trivial GLWEs, data_struct.rs:146-151), which discloses the AES key -- format comparisons only"""
         luts = np.zeros(lib().txc_lut_words(C.byref(self.p)), np.uint64)
         k = np.frombuffer(bytes(aes_key), np.uint8).copy()
-        lib().txc_make_round_luts(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk), _p64(luts))
+        _chk(lib().txc_make_round_luts_ex(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk),
+                                          C.c_uint(LUTS_REFERENCE_TRIVIAL if reference_trivial else 0), _p64(luts)),
+             "txc_make_round_luts")
         return luts
 
     def ctr_luts(self, aes_key, seed):
         luts = np.zeros(lib().txc_ctr_lut_words(C.byref(self.p)), np.uint64)
         k = np.frombuffer(bytes(aes_key), np.uint8).copy()
-        lib().txc_make_ctr_luts(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk), _p64(luts))
+        _chk(lib().txc_make_ctr_luts(C.byref(self.p), C.c_uint64(seed), _p8(k), _p64(self.glwe_sk), _p64(luts)),
+             "txc_make_ctr_luts")
         return luts
 
     def decrypt_bits(self, lwe):
@@ -61,7 +80,8 @@ class ClientKeys:
     def encrypt_bits(self, bits, seed):
         bits = np.ascontiguousarray(bits, np.uint8)
         out = np.zeros(bits.size * (self.p.k * self.p.N + 1), np.uint64)
-        lib().txc_encrypt_bits(C.byref(self.p), C.c_uint64(seed), _p64(self.glwe_sk), _p8(bits), C.c_size_t(bits.size), _p64(out))
+        _chk(lib().txc_encrypt_bits(C.byref(self.p), C.c_uint64(seed), _p64(self.glwe_sk), _p8(bits), C.c_size_t(bits.size),
+                                    _p64(out)), "txc_encrypt_bits")
         return out.reshape(bits.size, -1)
 
 

@@ -32,7 +32,7 @@ class TxTiming(C.Structure):
                                           "n_lut_eval", "n_linear")]
 
 
-EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys",
+EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys", "tx_eval_key_words",
            "tx_load_round_luts", "tx_load_ctr_luts", "tx_transcipher", "tx_transcipher_partial", "tx_max_u16",
            "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
@@ -55,7 +55,8 @@ def lib():
         L.tx_create.restype = C.c_void_p
         L.tx_create.argtypes = [C.POINTER(TxParams), C.c_int]
         L.tx_destroy.argtypes = [C.c_void_p]
-        L.tx_load_eval_keys.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p]
+        L.tx_load_eval_keys.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t]
+        L.tx_eval_key_words.argtypes = [C.c_void_p, C.POINTER(C.c_size_t * 4)]
         L.tx_load_round_luts.argtypes = [C.c_void_p, u64p, C.c_size_t]
         L.tx_load_ctr_luts.argtypes = [C.c_void_p, u64p, C.c_size_t]
         L.tx_transcipher.argtypes = [C.c_void_p, u8p, C.c_size_t, u8p, C.c_void_p, C.c_int]
@@ -114,8 +115,20 @@ class Engine:
         if rc != 0:
             raise TxError(lib().tx_last_error().decode())
 
+    def eval_key_words(self):
+        """word counts (bsk, ksk, auto, ss) the context expects"""
+        out = (C.c_size_t * 4)()
+        self._chk(lib().tx_eval_key_words(self.h, C.byref(out)))
+        return tuple(out)
+
     def load_eval_keys(self, bsk, ksk, auto_keys, ss_key):
-        self._chk(lib().tx_load_eval_keys(self.h, _p64(bsk), _p64(ksk), _p64(auto_keys), _p64(ss_key)))
+        ks = [np.ascontiguousarray(k) for k in (bsk, ksk, auto_keys, ss_key)]
+        for k, name in zip(ks, ("bsk", "ksk", "auto_keys", "ss_key")):
+            if k.dtype != np.uint64:
+                raise TxError("load_eval_keys: %s must be uint64 torus words, got %s" % (name, k.dtype))
+        # the library checks every length against the context's parameters before it reads anything
+        self._chk(lib().tx_load_eval_keys(self.h, _p64(ks[0]), ks[0].size, _p64(ks[1]), ks[1].size,
+                                          _p64(ks[2]), ks[2].size, _p64(ks[3]), ks[3].size))
 
     def load_round_luts(self, luts):
         self._chk(lib().tx_load_round_luts(self.h, _p64(luts), luts.size))

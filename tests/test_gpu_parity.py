@@ -248,6 +248,16 @@ def test_edge_cases_and_errors(rig256):
     e2 = txhip.Engine(txhip.aes_tight(n=256), 0)
     with pytest.raises(txhip.TxError, match="keys not loaded"):
         e2.transcipher(bytes(16))
+    # key material of the wrong length (a truncated file, keys for another n) is refused before anything is read
+    assert e2.eval_key_words() == (r.keys.bsk.size, r.keys.ksk.size, r.keys.auto.size, r.keys.ss.size)
+    with pytest.raises(txhip.TxError, match="key length mismatch"):
+        e2.load_eval_keys(r.keys.bsk[:-1], r.keys.ksk, r.keys.auto, r.keys.ss)
+    with pytest.raises(txhip.TxError, match="key length mismatch"):
+        e2.load_eval_keys(np.concatenate([r.keys.bsk, r.keys.bsk]), r.keys.ksk, r.keys.auto, r.keys.ss)   # n = 512 keys
+    with pytest.raises(txhip.TxError, match="uint64"):
+        e2.load_eval_keys(r.keys.bsk.astype(np.float64), r.keys.ksk, r.keys.auto, r.keys.ss)
+    with pytest.raises(txhip.TxError, match="keys not loaded"):
+        e2.transcipher(bytes(16))
     e2.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     with pytest.raises(txhip.TxError, match="LUTs not loaded"):
         e2.transcipher(bytes(16))
