@@ -124,8 +124,10 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
         hipMalloc(&c->unit_counter, 64) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR2) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR3) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR3) != hipSuccess) {
         fail("tx_create: cannot set up the persistent blind rotation"); delete c; return nullptr;
     }
     c->num_cus = prop.multiProcessorCount;
@@ -323,11 +325,12 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
-    if (c->br_variant == 2) {
-        hipMemsetAsync(c->unit_counter, 0, 4, c->stream);
-        const size_t wgs = std::min<size_t>((count + BR2_WAVES - 1) / BR2_WAVES, (size_t)c->num_cus);
-        hipLaunchKernelGGL(k_blind_rotate2, dim3(wgs), dim3(512), LDS_BYTES_BR2, c->stream, in, acc, (int)count,
-                           (int)c->p.n, c->bsk_f, c->tw, c->unit_counter);
+    if (c->br_variant == 4) {
+        hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
+                           (int)c->p.n, c->bsk_f, c->tw);
+    } else if (c->br_variant == 3) {
+        hipLaunchKernelGGL(k_blind_rotate3, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
+                           (int)c->p.n, c->bsk_f, c->tw);
     } else
     hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
                        (int)c->p.n, c->bsk_f, c->tw);

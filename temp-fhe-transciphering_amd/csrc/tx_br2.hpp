@@ -1,4 +1,4 @@
-// tx_br2.hpp -- blind rotation at TWO waves per SIMD (round 2).
+// tx_br2.hpp -- blind rotation at TWO waves per SIMD (round 2): k_blind_rotate3.
 //
 // Why: one wave alone on a SIMD issues one vector instruction per 4 cycles whatever its width, and every
 // LDS / memory round trip of that wave is exposed.  Two co-resident waves interleave: 32-bit instructions
@@ -8,22 +8,139 @@
 // What has to give: two waves per SIMD means 256 registers per wave and 8 accumulators per CU, and eight
 // 24 KiB accumulators do not fit the 160 KiB of LDS.  So the two MASK polynomials of the accumulator live in
 // registers (64) and only the BODY polynomial stays in LDS next to the wave's transpose tile:
-//   LDS  = twiddles 22.5 KiB + 8 x (tile 8.1 KiB + body 8 KiB) = 151.5 KiB, one 512-thread workgroup per CU;
 //   VGPR = mask 64 + three digit transforms 96 + ONE Fourier accumulator 32 + key 32 + temporaries.
 // The multiply-accumulate and the inverse transform therefore run column by column (same products, same
 // order, same arithmetic per polynomial as k_blind_rotate: bit-identical results).
 //
-// Work distribution: within a SIMD the older wave wins issue arbitration, so equal static shares would leave
-// the younger wave finishing alone; the waves take units from a global counter instead (persistent workgroups,
-// one per CU; every wave leaves the loop when the counter passes `count`).
+// Work distribution: within a SIMD the OLDER wave wins issue arbitration (measured: 29 k against 45 k cycles per
+// step), so two waves started together finish far apart.  Two 256-thread workgroups per CU instead of one of 512
+// threads make that imbalance harmless: every workgroup spends the first half of its life as the younger one and
+// the second half, after its neighbour has retired and a new one has arrived, as the older one; all workgroups
+// take the same time and every SIMD holds two waves until the grid drains.  That needs the workgroup's LDS image
+// in 80 KiB, see below.
 #pragma once
 #include "tx_kernels.hpp"
 
 namespace txd {
 
-constexpr int BR2_WAVES = 8;
-constexpr size_t BR2_WAVE_BYTES = SCRATCH_CPLX * sizeof(cplx) + (size_t)N * sizeof(uint64_t);
-constexpr size_t LDS_BYTES_BR2 = TW_ROWS * 64 * sizeof(cplx) + BR2_WAVES * BR2_WAVE_BYTES;
+// ---- LDS image of this kernel: 2 workgroups of 256 threads per CU, 80 KiB each ----
+//   twist 8 rows + pass-A 7 rows of 64 complex (as tx_device.hpp), pass-B 7 rows of EIGHT complex (the pass-B
+//   twiddle depends on lane & 7 only): 16 256 B; then per wave an UNPADDED 8 KiB transpose tile and the 8 KiB body.
+//   16 256 + 4 x 16 384 = 81 792 B <= 81 920 B.  The pitch-65 padding of tx_device.hpp (512 B per workgroup) would
+//   not fit, so the second exchange stores column (8g + r) ^ b of row b instead (XOR swizzle): 8 consecutive lanes
+//   of a ds_write_b128 still hit 8 distinct bank quads, and a ds_read_b128 reads lane ^ r', a permutation inside
+//   aligned groups of 8 columns, which keeps its 16-lane groups on 16 distinct quads.  The first exchange needs no
+//   skew at all: its 8-lane store groups are contiguous 128-byte runs.
+constexpr int BR3_TWB = 15 * 64;                             // first pass-B entry (complex units)
+constexpr int BR3_TW_CPLX = 15 * 64 + 7 * 8;
+constexpr size_t BR3_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)N * sizeof(uint64_t);
+constexpr size_t LDS_BYTES_BR3 = BR3_TW_CPLX * sizeof(cplx) + WAVES * BR3_WAVE_BYTES;
+static_assert(LDS_BYTES_BR3 <= 80 * 1024, "two workgroups per CU");
+
+struct Br3Ctx {
+    const cplx *tw;     // twist rows 0..7, pass-A rows 8..14 (row 7 + r), pass-B compact at BR3_TWB
+    cplx *tile;         // 512 complex, unpadded
+    uint64_t *pl;       // the tile as 1024 torus words
+    uint64_t *bl;       // body polynomial
+    int lane;
+};
+
+//   xchg_hi: element (lane = 8a+b, reg r)  ->  (lane = 8r+b, reg a)
+__device__ __forceinline__ void xchg_hi_s(cplx (&v)[8], cplx *tile, int lane)
+{
+    const int a = lane >> 3, b = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 8; r++) tile[a * 64 + 8 * r + b] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = tile[r * 64 + lane];
+    issue_fence();
+}
+//   xchg_lo: element (lane = 8g+b, reg r)  ->  (lane = 8g+r, reg b); column XOR-swizzled by the row
+__device__ __forceinline__ void xchg_lo_s(cplx (&v)[8], cplx *tile, int lane)
+{
+    const int g8 = lane & ~7, b = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 8; r++) tile[b * 64 + ((g8 + r) ^ b)] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = tile[r * 64 + (lane ^ r)];
+    issue_fence();
+}
+// same arithmetic per polynomial as fft_fwd / fft_inv (tx_device.hpp); twiddles are read where they are used
+__device__ __forceinline__ void fft_fwd_s(cplx (&v)[8], const Br3Ctx &w)
+{
+    const int lane = w.lane;
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = cmul(v[m], w.tw[m * 64 + lane]);
+    dft8<+1>(v);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w.tw[(7 + r) * 64 + lane]);
+    xchg_hi_s(v, w.tile, lane);
+    dft8<+1>(v);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w.tw[BR3_TWB + (r - 1) * 8 + (lane & 7)]);
+    xchg_lo_s(v, w.tile, lane);
+    dft8<+1>(v);
+}
+__device__ __forceinline__ void fft_inv_s(cplx (&v)[8], const Br3Ctx &w)
+{
+    const int lane = w.lane;
+    dft8<-1>(v);
+    xchg_lo_s(v, w.tile, lane);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], w.tw[BR3_TWB + (r - 1) * 8 + (lane & 7)]);
+    dft8<-1>(v);
+    xchg_hi_s(v, w.tile, lane);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], w.tw[(7 + r) * 64 + lane]);
+    dft8<-1>(v);
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = cmulc(v[m], w.tw[m * 64 + lane]);
+}
+// three polynomials together (software pipeline over the polynomials as fft_fwd_n)
+__device__ __forceinline__ void fft_fwd3_s(cplx (&v)[KP][8], const Br3Ctx &w)
+{
+    const int lane = w.lane;
+    {
+        cplx t[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) t[m] = w.tw[m * 64 + lane];
+        issue_fence();
+#pragma unroll
+        for (int p = 0; p < KP; p++)
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], t[m]);
+    }
+    {
+        cplx t[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) t[r - 1] = w.tw[(7 + r) * 64 + lane];
+        issue_fence();
+#pragma unroll
+        for (int p = 0; p < KP; p++) {
+            dft8<+1>(v[p]);
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], t[r - 1]);
+            xchg_hi_s(v[p], w.tile, lane);
+        }
+    }
+    {
+        cplx t[7];
+#pragma unroll
+        for (int r = 1; r < 8; r++) t[r - 1] = w.tw[BR3_TWB + (r - 1) * 8 + (lane & 7)];
+        issue_fence();
+#pragma unroll
+        for (int p = 0; p < KP; p++) {
+            dft8<+1>(v[p]);
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], t[r - 1]);
+            xchg_lo_s(v[p], w.tile, lane);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < KP; p++) dft8<+1>(v[p]);
+}
 
 // digits of  s(X) X^rot - own  for one polynomial whose natural-order image is in LDS at s
 __device__ __forceinline__ void br2_digits(const uint64_t *s, const uint64_t (&own)[16], uint32_t base, uint32_t thr, cplx (&d)[8])
@@ -41,133 +158,189 @@ __device__ __forceinline__ void br2_digits(const uint64_t *s, const uint64_t (&o
     }
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_blind_rotate2(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g,
-                     unsigned int *next_unit)
+#ifndef BR3_NUM_VGPR
+#define BR3_NUM_VGPR 256
+#endif
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(BR3_NUM_VGPR)))
+void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    WaveCtx w = wave_setup(tw_g, lds, BR2_WAVE_BYTES);
-    const int lane = w.lane;
-    uint64_t *bl = reinterpret_cast<uint64_t *>(w.tile + SCRATCH_CPLX);     // body polynomial, natural order
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    // tw_g is the [22][64] table of tx_api.hip: rows 0..14 as they are, rows 15..21 (pass B) depend on lane & 7 only
+    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * WAVES + wave;
+    if (unit >= count) return;
+    Br3Ctx w;
+    w.tw = tw;
+    w.tile = reinterpret_cast<cplx *>(lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES);
+    w.pl = reinterpret_cast<uint64_t *>(w.tile);
+    w.bl = w.pl + N;
+    w.lane = lane;
+    uint64_t *bl = w.bl;
     const uint32_t thr = 0x400000u - (uint32_t)(lane & 1);
-    for (;;) {
-        unsigned int u = 0;
-        if (lane == 0) u = atomicAdd(next_unit, 1u);
-        u = (unsigned int)__shfl((int)u, 0);
-        if (u >= (unsigned int)count) break;
-        const uint64_t *ct = lwe + (size_t)u * (n + 1);
-        uint64_t a0[16], a1[16];
-        {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
-            const int rot = 2 * N - (int)modswitch(ct[n]);
-#pragma unroll
-            for (int m = 0; m < 16; m++) {
-                int src = lane + 64 * m - rot;
-                uint64_t neg = 0;
-                if (src < 0) { src += N; neg = ~neg; }
-                if (src < 0) { src += N; neg = ~neg; }
-                uint64_t x = test_vector(src);
-                a0[m] = 0;
-                a1[m] = 0;
-                bl[lane + 64 * m] = (x ^ neg) - neg;
-            }
-        }
-        uint64_t cti = ct[0];
-        TXD_STAMP_DECL();
-#pragma unroll 1
-        for (int i = 0; i < n; i++) {
-            const uint32_t rot = modswitch(cti);
-            cti = ct[(i + 1 < n) ? i + 1 : i];              // next mask element: a step ahead of its use
-            const uint32_t base = ((uint32_t)lane - rot) & (2 * N - 1);
-            cplx d[KP][8];
-            // mask polynomials: staged through the tile for the rotation (lane permutation)
-            wave_lds_fence();
-#pragma unroll
-            for (int m = 0; m < 16; m++) w.pl[lane + 64 * m] = a0[m];
-            wave_lds_fence();
-            br2_digits(w.pl, a0, base, thr, d[0]);
-#ifdef BR2_SEQ_FWD
-            fft_fwd(d[0], w.tw, w.tile, lane);
-#endif
-            wave_lds_fence();
-#pragma unroll
-            for (int m = 0; m < 16; m++) w.pl[lane + 64 * m] = a1[m];
-            wave_lds_fence();
-            br2_digits(w.pl, a1, base, thr, d[1]);
-#ifdef BR2_SEQ_FWD
-            fft_fwd(d[1], w.tw, w.tile, lane);
-#endif
-            {
-                uint64_t own[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) own[m] = bl[lane + 64 * m];
-                br2_digits(bl, own, base, thr, d[2]);
-            }
-            wave_lds_fence();
-            TXD_STAMP(0);
-#ifdef BR2_SEQ_FWD
-            fft_fwd(d[2], w.tw, w.tile, lane);
-#else
-            fft_fwd_n<KP>(d, w.tw, w.tile, lane);
-#endif
-            TXD_STAMP(1);
-            const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
-#pragma unroll
-            for (int c = 0; c < KP; c++) {
-                cplx F[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) F[r] = make_double2(0.0, 0.0);
-                cplx g[8];
-                load_key8(g, row + (size_t)c * H, lane);
-#pragma unroll
-                for (int q = 0; q < KP; q++) {
-#ifdef BR2_NO_PREFETCH
-                    fmac8r(F, d[q], g);
-                    if (q + 1 < KP) load_key8(g, row + ((size_t)(q + 1) * KP + c) * H, lane);
-#else
-                    cplx gn[8];
-                    if (q + 1 < KP) load_key8(gn, row + ((size_t)(q + 1) * KP + c) * H, lane);
-                    fmac8r(F, d[q], g);
-                    if (q + 1 < KP) {
-#pragma unroll
-                        for (int r = 0; r < 8; r++) g[r] = gn[r];
-                    }
-#endif
-                }
-                TXD_STAMP(2);
-                fft_inv(F, w.tw, w.tile, lane);
-                TXD_STAMP(3);
-                if (c == 0) {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) { a0[m] = torus_add_f64(a0[m], F[m].x); a0[m + 8] = torus_add_f64(a0[m + 8], F[m].y); }
-                } else if (c == 1) {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) { a1[m] = torus_add_f64(a1[m], F[m].x); a1[m + 8] = torus_add_f64(a1[m + 8], F[m].y); }
-                } else {
-                    uint64_t cur[16];
-                    wave_lds_fence();
-#pragma unroll
-                    for (int m = 0; m < 16; m++) cur[m] = bl[lane + 64 * m];
-                    issue_fence();
-#pragma unroll
-                    for (int m = 0; m < 8; m++) {
-                        bl[lane + 64 * m] = torus_add_f64(cur[m], F[m].x);
-                        bl[lane + 64 * (m + 8)] = torus_add_f64(cur[m + 8], F[m].y);
-                    }
-                }
-                TXD_STAMP(4);
-            }
-        }
-        TXD_STAMP_FLUSH(n);
-        wave_lds_fence();
-        uint64_t *o = acc_out + (size_t)u * GL;
+    const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+    uint64_t a0[16], a1[16];
+    {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+        const int rot = 2 * N - (int)modswitch(ct[n]);
 #pragma unroll
         for (int m = 0; m < 16; m++) {
-            o[lane + 64 * m] = a0[m];
-            o[N + lane + 64 * m] = a1[m];
-            o[2 * N + lane + 64 * m] = bl[lane + 64 * m];
+            int src = lane + 64 * m - rot;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            a0[m] = 0;
+            a1[m] = 0;
+            bl[lane + 64 * m] = (x ^ neg) - neg;
+        }
+    }
+    uint64_t cti = ct[0];
+    TXD_STAMP_DECL();
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const uint32_t rot = modswitch(cti);
+        cti = ct[(i + 1 < n) ? i + 1 : i];              // next mask element: a step ahead of its use
+        const uint32_t base = ((uint32_t)lane - rot) & (2 * N - 1);
+        cplx d[KP][8];
+        // mask polynomials: staged through the tile for the rotation (a lane permutation)
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < 16; m++) w.pl[lane + 64 * m] = a0[m];
+        wave_lds_fence();
+        br2_digits(w.pl, a0, base, thr, d[0]);
+#ifdef BR3_SEQ
+        wave_lds_fence();
+        fft_fwd_s(d[0], w);
+        issue_fence();
+#endif
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < 16; m++) w.pl[lane + 64 * m] = a1[m];
+        wave_lds_fence();
+        br2_digits(w.pl, a1, base, thr, d[1]);
+#ifdef BR3_SEQ
+        wave_lds_fence();
+        fft_fwd_s(d[1], w);
+        issue_fence();
+#endif
+        {
+            uint64_t own[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) own[m] = bl[lane + 64 * m];
+            br2_digits(bl, own, base, thr, d[2]);
         }
         wave_lds_fence();
+        TXD_STAMP(0);
+#ifdef BR3_SEQ
+        fft_fwd_s(d[2], w);
+        issue_fence();
+#else
+        fft_fwd3_s(d, w);
+#endif
+        TXD_STAMP(1);
+        const cplx *row = bsk_f + (size_t)i * KP * KP * H;  // [row q][col c][512]
+#pragma unroll
+        for (int c = 0; c < KP; c++) {
+            cplx F[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) F[r] = make_double2(0.0, 0.0);
+            cplx g[8];
+            load_key8(g, row + (size_t)c * H, lane);
+#pragma unroll
+            for (int q = 0; q < KP; q++) {
+#ifdef BR3_SEQ
+                fmac8r(F, d[q], g);
+                issue_fence();
+                if (q + 1 < KP) load_key8(g, row + ((size_t)(q + 1) * KP + c) * H, lane);
+#else
+                cplx gn[8];
+                if (q + 1 < KP) load_key8(gn, row + ((size_t)(q + 1) * KP + c) * H, lane);
+                fmac8r(F, d[q], g);
+                if (q + 1 < KP) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) g[r] = gn[r];
+                }
+#endif
+            }
+            TXD_STAMP(2);
+            fft_inv_s(F, w);
+            TXD_STAMP(3);
+            if (c == 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) { a0[m] = torus_add_f64(a0[m], F[m].x); a0[m + 8] = torus_add_f64(a0[m + 8], F[m].y); }
+            } else if (c == 1) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) { a1[m] = torus_add_f64(a1[m], F[m].x); a1[m + 8] = torus_add_f64(a1[m + 8], F[m].y); }
+            } else {
+                uint64_t cur[16];
+                wave_lds_fence();
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = bl[lane + 64 * m];
+                issue_fence();
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    bl[lane + 64 * m] = torus_add_f64(cur[m], F[m].x);
+                    bl[lane + 64 * (m + 8)] = torus_add_f64(cur[m + 8], F[m].y);
+                }
+            }
+            TXD_STAMP(4);
+        }
     }
+    TXD_STAMP_FLUSH(n);
+    wave_lds_fence();
+    uint64_t *o = acc_out + (size_t)unit * GL;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        o[lane + 64 * m] = a0[m];
+        o[N + lane + 64 * m] = a1[m];
+        o[2 * N + lane + 64 * m] = bl[lane + 64 * m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blind_rotate4: the same kernel with the CMux loop as generated assembly (tools/asmgen/brgen.py ->
+// tx_br_asm.inc): fixed register map (256 VGPRs, nothing in scratch), counted waits, key ring of 12 complex
+// registers.  The HIP part loads the twiddles, builds the rotated test vector in the wave's LDS slice and hands
+// five scalars to the loop; the loop stores the accumulator itself.  Same LDS image as k_blind_rotate3.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2)
+void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * WAVES + wave;
+    if (unit >= count) return;
+    unsigned char *tile = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES;
+    uint64_t *bl = reinterpret_cast<uint64_t *>(tile) + N;
+    const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+    {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+        const int rot = 2 * N - (int)modswitch(ct[n]);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int src = lane + 64 * m - rot;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            bl[lane + 64 * m] = (x ^ neg) - neg;
+        }
+    }
+    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
+    uint64_t *out = acc_out + (size_t)unit * GL;
+    asm volatile(
+#include "tx_br_asm.inc"
+        :
+        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr)
+        :
+#include "tx_br_asm_clobbers.inc"
+    );
 }
 
 }  // namespace txd

@@ -1,0 +1,556 @@
+"""Generator of the blind-rotation CMux loop as gfx950 assembly (two waves per SIMD, 256 VGPRs per wave).
+
+hipcc cannot hold this kernel's working set in 256 registers (it spills 50-100 registers to scratch and the
+scratch traffic shares the vector-memory counter with the key stream), so the loop is emitted with a fixed
+register map, explicit software pipelining and counted waits.  The arithmetic is, operation for operation, the
+one of k_blind_rotate / the CPU oracle (oracle/txo_fft.c, txo_core.c): same butterfly network, same fma
+placement, same summation order -- outputs are bit-identical.  tools/asmgen/test_emu.py runs the emitted
+stream in a lane-exact emulator (gcn.py) against the oracle's primitives; tests/test_gpu_parity.py compares the
+kernel with the oracle on the GPU.
+
+    python3 tools/asmgen/brgen.py > temp-fhe-transciphering_amd/csrc/tx_br_asm.inc
+
+Register map (VGPR):
+    0 lane          1 tile + lane*8      2 tile + lane*16     3 lane*16 (twiddle row / key offset)
+    4 lane*16+4096  5 pass-B twiddle     6 xchg_hi store      7 xchg_lo store (xor r<<4)
+    8 e = 1-(lane&1)                     9 lane*8 (epilogue)  10,11 next mask element / hb, lb8
+    12:13, 14:15 temporaries T0, T1
+    16..47 A0   48..79 A1   (mask polynomials of the accumulator, 16 x u64 each)
+    80..111 D0  112..143 D1  144..175 D2   (digit polynomials -> their transforms, 8 complex each)
+    176..207 F  (Fourier accumulator of one column; rotation addresses + sign masks before the MAC)
+    208..255 X  (key ring in the MAC; twiddles + spare quad in the transforms; body words in the rotation)
+SGPR: see `SG` below.  LDS image: tx_br2.hpp (twiddles at 0, per wave: 8 KiB unpadded tile + 8 KiB body).
+"""
+import struct
+import sys
+from gcn import V, S, Lit, VCC, Prog
+
+N, LOGN, H, KP = 1024, 10, 512, 3
+TWB = 15 * 64 * 16                      # byte offset of the compact pass-B twiddles
+
+# ---- register map
+LANE, L8T, L16T, L16, OFF1, TWBA, XHW, XLW, EREG, L8, R10, R11 = [V(i) for i in range(12)]
+T0, T1 = V(12, 2), V(14, 2)
+A = [16, 48]
+D = [80, 112, 144]
+F = 176
+X = 208
+RA = [V(176 + m) for m in range(16)]        # rotation addresses (phase R only)
+SGN = [V(192 + m) for m in range(16)]       # sign masks (phase R only)
+
+
+class SG:
+    CT = S(34, 2); ROW = S(36, 2); OUT = S(38, 2)
+    NSTEP = S(40); I = S(41); TILE = S(42); ROT = S(43); CTV = S(44, 2); TMP = S(46); TMP2 = S(47)
+    C_2M64 = S(48, 2); C_M2P64 = S(50, 2); C_84 = S(52, 2); C_52 = S(54, 2); C_SQH = S(56, 2); C_M4338 = S(58)
+    KP0 = S(60, 2); KP1 = S(62, 2); KP2 = S(64, 2); KPN = S(66, 2)
+
+
+def f64bits(x): return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def quad(base, r): return V(base + 4 * r, 4)
+def qre(q): return V(q.i, 2)
+def qim(q): return V(q.i + 2, 2)
+
+
+class Cx:
+    """view of a complex value: each component is a 64-bit register pair with an optional negation"""
+    def __init__(self, re, im, q=None): self.re, self.im, self.q = re, im, q
+    @staticmethod
+    def of(q): return Cx(qre(q), qim(q), q)
+    def mul_i(self): return Cx(-self.im, self.re, self.q)         # * i   (a view: same quad)
+    def mul_mi(self): return Cx(self.im, -self.re, self.q)        # * -i
+
+
+class Gen:
+    def __init__(self):
+        self.p = Prog()
+        self.vmq = []          # in-flight vector-memory ops, oldest first: sets of destination registers
+        self.lgq = []
+
+    # ---------------------------------------------------------------- emission + counters
+    def e(self, op, *a, **kw): self.p.emit(op, *a, **kw)
+    def c(self, t): self.p.comment(t)
+
+    def _wait(self, q, regs, limit):
+        regs = set(regs)
+        idx = -1
+        for k, r in enumerate(q):
+            if r & regs: idx = k
+        if idx < 0: return None
+        keep = min(len(q) - (idx + 1), limit)
+        del q[:len(q) - keep]
+        return keep
+
+    def vm_wait(self, regs):
+        k = self._wait(self.vmq, regs, 63)
+        if k is not None: self.e("s_waitcnt", vm=k)
+
+    def lg_wait(self, regs):
+        k = self._wait(self.lgq, regs, 15)
+        if k is not None: self.e("s_waitcnt", lgkm=k)
+
+    def lg_wait_all(self):
+        if self.lgq:
+            self.e("s_waitcnt", lgkm=0); self.lgq.clear()
+
+    def vm_wait_all(self):
+        if self.vmq:
+            self.e("s_waitcnt", vm=0); self.vmq.clear()
+
+    @staticmethod
+    def regs(v): return set(range(v.i, v.i + v.n))
+
+    def ds_read(self, op, d, addr, offset=0):
+        self.e(op, d, addr, offset=offset); self.lgq.append(self.regs(d))
+
+    def ds_write(self, op, addr, src, offset=0):
+        self.e(op, addr, src, offset=offset); self.lgq.append(set())
+
+    def gload(self, op, d, voff, sbase, offset=0):
+        self.e(op, d, voff, sbase, offset=offset); self.vmq.append(self.regs(d))
+
+    def gstore(self, op, voff, src, sbase, offset=0):
+        self.e(op, voff, src, sbase, offset=offset); self.vmq.append(set())
+
+    # ---------------------------------------------------------------- complex helpers (bit-exact op order)
+    def cadd_to(self, dst, x, y):      # dst = x + y   (dst quad; x, y views)
+        self.e("v_add_f64", qre(dst), x.re, y.re)
+        self.e("v_add_f64", qim(dst), x.im, y.im)
+
+    def csub_to(self, dst, x, y):
+        self.e("v_add_f64", qre(dst), x.re, -y.re)
+        self.e("v_add_f64", qim(dst), x.im, -y.im)
+
+    def bfly(self, x, y, spare):
+        """(x, y) -> (x + y in x's quad, x - y in `spare`); returns (sum, diff, freed quad of y or None).
+        x must be a plain view of its quad; y may be any view."""
+        assert x.q is not None and not x.re.neg and not x.im.neg
+        self.csub_to(spare, x, y)
+        self.cadd_to(x.q, x, y)
+        return Cx.of(x.q), Cx.of(spare), y.q
+
+    def cmul(self, q, w, tmp):         # q *= w        cmul(): t = y*wy; u = y*wx; re = fma(x, wx, -t); im = fma(x, wy, u)
+        x, y, wx, wy = qre(q), qim(q), qre(w), qim(w)
+        self.e("v_mul_f64", tmp, y, wy)
+        self.e("v_mul_f64", y, y, wx)
+        self.e("v_fma_f64", y, x, wy, y)
+        self.e("v_fma_f64", x, x, wx, -tmp)
+
+    def cmulc(self, q, w, tmp, tmp2):  # q *= conj(w)  cmulc(): t = y*wy; u = x*wy; re = fma(x, wx, t); im = fma(y, wx, -u)
+        x, y, wx, wy = qre(q), qim(q), qre(w), qim(w)
+        self.e("v_mul_f64", tmp, y, wy)
+        self.e("v_mul_f64", tmp2, x, wy)
+        self.e("v_fma_f64", y, y, wx, -tmp2)
+        self.e("v_fma_f64", x, x, wx, tmp)
+
+    def dft8(self, v, spare, sign):
+        """8-point DFT of the complex values in quads v[0..7] (dft8<sign> of tx_device.hpp, same pairing).
+        Returns (list of quads holding outputs 0..7, the new spare quad)."""
+        tmp = T0
+        a, b = [None] * 4, [None] * 4
+        for i in range(4):
+            a[i], b[i], fr = self.bfly(Cx.of(v[i]), Cx.of(v[i + 4]), spare)
+            spare = fr
+        c = SG.C_SQH
+        b1, b3 = b[1].q, b[3].q
+        if sign > 0:
+            # t1 = ((b1.x - b1.y) c, (b1.x + b1.y) c)
+            self.e("v_add_f64", tmp, qre(b1), -qim(b1))
+            self.e("v_add_f64", qim(b1), qre(b1), qim(b1))
+            self.e("v_mul_f64", qre(b1), tmp, c)
+            self.e("v_mul_f64", qim(b1), qim(b1), c)
+            t1 = Cx.of(b1)
+            t2 = b[2].mul_i()                                  # (-b2.y, b2.x)
+            # t3 = (-((b3.x + b3.y) c), (b3.x - b3.y) c)
+            self.e("v_add_f64", tmp, qre(b3), qim(b3))
+            self.e("v_add_f64", qim(b3), qre(b3), -qim(b3))
+            self.e("v_mul_f64", qre(b3), tmp, c)
+            self.e("v_mul_f64", qim(b3), qim(b3), c)
+            t3 = Cx(-qre(b3), qim(b3), b3)
+        else:
+            # t1 = ((b1.x + b1.y) c, (b1.y - b1.x) c)
+            self.e("v_add_f64", tmp, qre(b1), qim(b1))
+            self.e("v_add_f64", qim(b1), qim(b1), -qre(b1))
+            self.e("v_mul_f64", qre(b1), tmp, c)
+            self.e("v_mul_f64", qim(b1), qim(b1), c)
+            t1 = Cx.of(b1)
+            t2 = b[2].mul_mi()                                 # (b2.y, -b2.x)
+            # t3 = ((b3.y - b3.x) c, -((b3.x + b3.y) c))
+            self.e("v_add_f64", tmp, qim(b3), -qre(b3))
+            self.e("v_add_f64", qim(b3), qre(b3), qim(b3))
+            self.e("v_mul_f64", qre(b3), tmp, c)
+            self.e("v_mul_f64", qim(b3), qim(b3), c)
+            t3 = Cx(qre(b3), -qim(b3), b3)
+        out = [None] * 8
+
+        def four(x0, x1, x2, x3, o0, o1, o2, o3, spare):
+            # p0 = x0 + x2; q0 = x0 - x2; p1 = x1 + x3; d = x1 - x3; q1 = +-i d; o0 = p0 + p1; o1 = p0 - p1; o2 = q0 + q1; o3 = q0 - q1
+            p0, q0, fr = self.bfly(x0, x2, spare); spare = fr
+            p1, d, fr = self.bfly(x1, x3, spare); spare = fr
+            q1 = d.mul_i() if sign > 0 else d.mul_mi()
+            r0, r1, fr = self.bfly(p0, p1, spare); spare = fr
+            r2, r3, fr = self.bfly(q0, q1, spare); spare = fr
+            out[o0], out[o1], out[o2], out[o3] = r0.q, r1.q, r2.q, r3.q
+            return spare
+        spare = four(a[0], a[1], a[2], a[3], 0, 4, 2, 6, spare)
+        spare = four(b[0], t1, t2, t3, 1, 5, 3, 7, spare)
+        return out, spare
+
+    def home(self, v, spare, lo, hi):
+        """after a dft8 that is not followed by an exchange: if an output lives in the foreign spare quad (outside
+        registers lo..hi-1), move it into the free quad of the home region so that the foreign quad is free again"""
+        for k in range(8):
+            if not (lo <= v[k].i < hi):
+                assert lo <= spare.i < hi
+                self.e("v_mov_b64", qre(spare), qre(v[k]))
+                self.e("v_mov_b64", qim(spare), qim(v[k]))
+                v[k], spare = spare, v[k]
+        return v, spare
+
+    # ---------------------------------------------------------------- LDS tile exchanges (unpadded, tx_br2.hpp)
+    def xchg_hi_write(self, v):
+        for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
+
+    def xchg_read(self, dst, swz):
+        for r in range(8):
+            if swz:
+                self.e("v_xor_b32", T1.lo(), Lit(r << 4), L16T)
+                self.ds_read("ds_read_b128", dst[r], T1.lo(), offset=1024 * r)
+            else:
+                self.ds_read("ds_read_b128", dst[r], L16T, offset=1024 * r)
+
+    def xchg_lo_write(self, v):
+        for r in range(8):
+            self.e("v_xor_b32", T1.lo(), Lit(r << 4), XLW)
+            self.ds_write("ds_write_b128", T1.lo(), v[r], offset=0)
+
+    def load_tw(self, dst, row0, nrows, compact=False):
+        """twiddle rows row0.. into quads dst[0..nrows-1]"""
+        for k in range(nrows):
+            if compact: self.ds_read("ds_read_b128", dst[k], TWBA, offset=128 * k)
+            else: self.ds_read("ds_read_b128", dst[k], L16, offset=1024 * (row0 + k))
+
+    # ---------------------------------------------------------------- forward transforms, three polynomials together
+    def fwd3(self, polys, xq):
+        """polys: three lists of 8 quads (digits as doubles); xq: 12 free quads of region X.
+        On return polys[p][r] is the quad holding F-layout register r of polynomial p."""
+        tw, spare = xq[:8], xq[8]
+        self.c("forward x3: twist")
+        self.load_tw(tw, 0, 8)
+        for p in range(3):
+            for m in range(8):
+                self.lg_wait(self.regs(tw[m]))
+                self.cmul(polys[p][m], tw[m], T0)
+        self.c("forward x3: pass 1 (dft8, pass-A twiddles, exchange hi)")
+        self.load_tw(tw, 8, 7)
+        for p in range(3):
+            polys[p], spare = self.dft8(polys[p], spare, +1)
+            for r in range(1, 8):
+                self.lg_wait(self.regs(tw[r - 1]))
+                self.cmul(polys[p][r], tw[r - 1], T0)
+            self.xchg_hi_write(polys[p])
+            # the stores captured their data: the eight quads + the spare are free; read back into a canonical set
+            free = sorted(polys[p] + [spare], key=lambda q: q.i)
+            polys[p], spare = free[:8], free[8]
+            self.xchg_read(polys[p], swz=False)
+        self.c("forward x3: pass 2 (dft8, pass-B twiddles, exchange lo)")
+        self.load_tw(tw, 0, 7, compact=True)
+        for p in range(3):
+            self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
+            polys[p], spare = self.dft8(polys[p], spare, +1)
+            for r in range(1, 8):
+                self.lg_wait(self.regs(tw[r - 1]))
+                self.cmul(polys[p][r], tw[r - 1], T0)
+            self.xchg_lo_write(polys[p])
+            free = sorted(polys[p] + [spare], key=lambda q: q.i)
+            polys[p], spare = free[:8], free[8]
+            self.xchg_read(polys[p], swz=True)
+        self.c("forward x3: pass 3 (dft8)")
+        for p in range(3):
+            self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
+            polys[p], spare = self.dft8(polys[p], spare, +1)
+            polys[p], spare = self.home(polys[p], spare, D[p], D[p] + 32)
+        return polys, spare
+
+    def inv1(self, v, xq):
+        """unnormalised inverse of one polynomial (fft_inv); v: 8 quads, xq: free quads of X (>= 9)."""
+        tw, spare = xq[:8], xq[8]
+        self.c("inverse: pass 3' (dft8, exchange lo)")
+        self.load_tw(tw, 0, 7, compact=True)                   # in flight during the butterflies
+        v, spare = self.dft8(v, spare, -1)
+        self.xchg_lo_write(v)
+        free = sorted(v + [spare], key=lambda q: q.i)
+        v, spare = free[:8], free[8]
+        self.xchg_read(v, swz=True)
+        self.lg_wait(set().union(*[self.regs(q) for q in v]))
+        self.c("inverse: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
+        for r in range(1, 8):
+            self.lg_wait(self.regs(tw[r - 1]))
+            self.cmulc(v[r], tw[r - 1], T0, T1)
+        self.load_tw(tw, 8, 7)
+        v, spare = self.dft8(v, spare, -1)
+        self.xchg_hi_write(v)
+        free = sorted(v + [spare], key=lambda q: q.i)
+        v, spare = free[:8], free[8]
+        self.xchg_read(v, swz=False)
+        self.lg_wait(set().union(*[self.regs(q) for q in v]))
+        self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist)")
+        for r in range(1, 8):
+            self.lg_wait(self.regs(tw[r - 1]))
+            self.cmulc(v[r], tw[r - 1], T0, T1)
+        self.load_tw(tw, 0, 8)
+        v, spare = self.dft8(v, spare, -1)
+        v, spare = self.home(v, spare, F, F + 32)
+        for m in range(8):
+            self.lg_wait(self.regs(tw[m]))
+            self.cmulc(v[m], tw[m], T0, T1)
+        return v, spare
+
+    # ---------------------------------------------------------------- integer <-> double
+    def digit_pair(self, q, own_lo, own_hi, sgn):
+        """q holds a rotated torus word in (q.i, q.i+1): replace it by the f64 digit of (+-word - own).
+        pbs_digit of tx_kernels.hpp (B = 23, one level, balanced top tie)."""
+        lo, hi, t = V(q.i), V(q.i + 1), T0.lo()
+        self.e("v_xor_b32", lo, lo, sgn)
+        self.e("v_xor_b32", hi, hi, sgn)
+        self.e("v_sub_co_u32", lo, VCC, lo, sgn)
+        self.e("v_subb_co_u32", hi, VCC, hi, sgn, VCC)
+        self.e("v_sub_co_u32", lo, VCC, lo, own_lo)
+        self.e("v_subb_co_u32", hi, VCC, hi, own_hi, VCC)
+        self.e("v_add_u32", t, Lit(0x100), hi)
+        self.e("v_bfe_u32", t, t, Lit(9), Lit(23))
+        self.e("v_sub_u32", t, t, EREG)
+        self.e("v_bfe_i32", t, t, Lit(0), Lit(23))
+        self.e("v_add_u32", t, t, EREG)
+        self.e("v_cvt_f64_i32", V(q.i, 2), t)
+
+    def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB):
+        """dst = cur + round-half-even(x) mod 2^64 (torus_add_f64 of tx_device.hpp); x: f64 pair (destroyed);
+        tA, tB: temporary pairs"""
+        self.e("v_mul_f64", tA, x, SG.C_2M64)
+        self.e("v_rndne_f64", tA, tA)
+        self.e("v_fma_f64", x, tA, SG.C_M2P64, x)              # ys
+        self.e("v_add_f64", tA, x, SG.C_84)                    # t1
+        self.e("v_add_f64", tB, tA, -SG.C_84)                  # h
+        self.e("v_add_f64", x, x, -tB)                         # lo
+        self.e("v_add_f64", x, x, SG.C_52)                     # t2
+        self.e("v_add3_u32", tA.lo(), tA.lo(), x.hi(), SG.C_M4338)     # rhi = bits(t1).lo + bits(t2).hi - 0x43380000
+        self.e("v_add_co_u32", dst_lo, VCC, cur_lo, x.lo())
+        self.e("v_addc_co_u32", dst_hi, VCC, cur_hi, tA.lo(), VCC)
+
+    # ---------------------------------------------------------------- the kernel
+    def prologue(self):
+        e = self.e
+        self.c("---- prologue: lane-dependent addresses, constants, accumulator mask = 0")
+        e("s_waitcnt", vm=0, lgkm=0)
+        e("v_mbcnt_lo_u32_b32", LANE, Lit(-1), Lit(0))
+        e("v_mbcnt_hi_u32_b32", LANE, Lit(-1), LANE)
+        e("v_lshl_add_u32", L8T, LANE, Lit(3), SG.TILE)
+        e("v_lshl_add_u32", L16T, LANE, Lit(4), SG.TILE)
+        e("v_lshlrev_b32", L16, Lit(4), LANE)
+        e("v_add_u32", OFF1, Lit(4096), L16)
+        e("v_and_b32", T0.lo(), Lit(7), LANE)                   # b
+        e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
+        e("v_add_u32", TWBA, Lit(TWB), TWBA)
+        e("v_lshrrev_b32", T0.hi(), Lit(3), LANE)               # a
+        e("v_lshl_add_u32", T0.hi(), T0.hi(), Lit(6), T0.lo())  # a*64 + b
+        e("v_lshl_add_u32", XHW, T0.hi(), Lit(4), SG.TILE)
+        e("v_and_b32", T1.lo(), Lit(0x38), LANE)                # g8
+        e("v_lshl_add_u32", T1.lo(), T0.lo(), Lit(6), T1.lo())  # b*64 + g8
+        e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
+        e("v_lshlrev_b32", T1.hi(), Lit(4), T0.lo())            # b << 4
+        e("v_or_b32", XLW, XLW, T1.hi())
+        e("v_and_b32", T0.lo(), Lit(1), LANE)
+        e("v_sub_u32", EREG, Lit(1), T0.lo())
+        e("v_lshlrev_b32", L8, Lit(3), LANE)
+        for name, val in (("C_2M64", 2.0 ** -64), ("C_M2P64", -(2.0 ** 64)), ("C_84", 1.5 * 2.0 ** 84), ("C_52", 1.5 * 2.0 ** 52),
+                          ("C_SQH", 0.70710678118654752440)):
+            s, b = getattr(SG, name), f64bits(val)
+            e("s_mov_b32", s.lo(), Lit(b & 0xFFFFFFFF)); e("s_mov_b32", s.hi(), Lit(b >> 32))
+        e("s_mov_b32", SG.C_M4338, Lit((-0x43380000) & 0xFFFFFFFF))
+        for q in range(2):
+            for m in range(32): e("v_mov_b32", V(A[q] + m), Lit(0))
+        e("v_mov_b32", R10, Lit(0))
+        self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0 (voffset register = its own dst: read at issue)
+        e("s_mov_b32", SG.I, Lit(0))
+
+    def step(self):
+        e = self.e
+        self.p.label("L_step%=")
+        # ---- rotation amount of this step (wave-uniform), prefetch of the next mask element
+        self.c("---- modswitch(ct[i]) -> rot; base = (lane - rot) mod 2N")
+        # loop head: the only vector-memory operation that can be in flight is the load of this step's mask element
+        # (from the prologue on entry; on the back edge it retired behind the key loads).  A full wait makes both
+        # entries the same state.
+        self.e("s_waitcnt", vm=0); self.vmq.clear()
+        e("v_readfirstlane_b32", SG.CTV.hi(), R11)
+        e("s_nop", Lit(3))
+        e("s_lshr_b32", SG.TMP, SG.CTV.hi(), Lit(23))           # x >> 55
+        e("s_and_b32", SG.TMP2, SG.TMP, Lit(1))
+        e("s_add_u32", SG.TMP, SG.TMP, SG.TMP2)
+        e("s_lshr_b32", SG.TMP, SG.TMP, Lit(1))
+        e("s_lshl_b32", SG.ROT, SG.TMP, Lit(3))
+        e("v_subrev_u32", T0.lo(), SG.ROT, LANE)
+        e("v_and_b32", T0.lo(), Lit(2 * N - 1), T0.lo())        # base
+        e("v_lshrrev_b32", R10, Lit(6), T0.lo())                # hb
+        e("v_and_b32", R11, Lit(63), T0.lo())
+        e("v_lshl_add_u32", R11, R11, Lit(3), SG.TILE)          # tile + (base & 63) * 8
+        for m in range(16):
+            t = T0.hi()
+            e("v_add_u32", t, Lit(m), R10)
+            e("v_bfe_i32", SGN[m], t, Lit(4), Lit(1))           # 0 / -1: coefficient comes from the negated half
+            e("v_and_b32", t, Lit(15), t)
+            e("v_lshl_add_u32", RA[m], t, Lit(9), R11)
+        # next mask element (index min(i+1, n-1)), a step ahead of its use
+        e("s_add_u32", SG.TMP, SG.I, Lit(1))
+        e("s_cmp_lt_u32", SG.TMP, SG.NSTEP)
+        e("s_cbranch_scc1", "L_nx%=")
+        e("s_mov_b32", SG.TMP, SG.I)
+        self.p.label("L_nx%=")
+        e("s_lshl_b32", SG.TMP, SG.TMP, Lit(3))
+        e("v_mov_b32", R10, SG.TMP)
+        self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)
+        # ---- stage the mask polynomials through the tile, gather the rotated words (in-order LDS: no waits in between)
+        self.c("---- rotation: stage mask polynomials in the tile, gather rotated coefficients")
+        xq = [quad(X, r) for r in range(12)]
+        for q in range(2):
+            for m in range(16): self.ds_write("ds_write_b64", L8T, V(A[q] + 2 * m, 2), offset=512 * m)
+            for m in range(8):
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m, 2), RA[m], offset=0)
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m + 2, 2), RA[m + 8], offset=0)
+        OWN = [V(X + 2 * j, 2) for j in range(16)]              # body words of this lane
+        for j in range(16): self.ds_read("ds_read_b64", OWN[j], L8T, offset=8192 + 512 * j)
+        for m in range(8):
+            self.ds_read("ds_read_b64", V(D[2] + 4 * m, 2), RA[m], offset=8192)
+            self.ds_read("ds_read_b64", V(D[2] + 4 * m + 2, 2), RA[m + 8], offset=8192)
+        self.c("---- digits: ct1 = acc X^rot - acc, one level (B = 23), as f64")
+        for q in range(3):
+            for m in range(8):
+                for half in range(2):
+                    j = m + 8 * half
+                    slot = V(D[q] + 4 * m + 2 * half, 2)
+                    self.lg_wait(self.regs(slot))
+                    if q < 2: ol, oh = V(A[q] + 2 * j), V(A[q] + 2 * j + 1)
+                    else:
+                        self.lg_wait(self.regs(OWN[j]))
+                        ol, oh = OWN[j].lo(), OWN[j].hi()
+                    self.digit_pair(slot, ol, oh, SGN[j])
+        # ---- forward transforms
+        polys = [[quad(D[p], r) for r in range(8)] for p in range(3)]
+        polys, spare = self.fwd3(polys, xq)
+        # ---- per column: multiply-accumulate against the key, inverse transform, update
+        for col in range(3):
+            self.c("---- column %d: F = sum_q D_q * key[q][col]" % col)
+            for q in range(3):
+                kp = (SG.KP0, SG.KP1, SG.KP2)[q]
+                e("s_add_u32", kp.lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
+                e("s_addc_u32", kp.hi(), SG.ROW.hi(), Lit(0))
+            NG = 12
+            ring = [quad(X, r) for r in range(NG)]
+            stream = [(q, r) for q in range(3) for r in range(8)]
+
+            def issue(k):
+                q, r = stream[k]
+                kp = (SG.KP0, SG.KP1, SG.KP2)[q]
+                self.gload("global_load_dwordx4", ring[k % NG], L16 if r < 4 else OFF1, kp, offset=(r & 3) * 1024)
+            for k in range(NG): issue(k)
+            Fq = [quad(F, r) for r in range(8)]
+            for k, (q, r) in enumerate(stream):
+                g = ring[k % NG]
+                self.vm_wait(self.regs(g))
+                d = polys[q][r]
+                re0 = Lit(0, f64=0.0) if q == 0 else qre(Fq[r])
+                im0 = Lit(0, f64=0.0) if q == 0 else qim(Fq[r])
+                e("v_fma_f64", qre(Fq[r]), qre(d), qre(g), re0)
+                e("v_fma_f64", qre(Fq[r]), -qim(d), qim(g), qre(Fq[r]))
+                e("v_fma_f64", qim(Fq[r]), qre(d), qim(g), im0)
+                e("v_fma_f64", qim(Fq[r]), qim(d), qre(g), qim(Fq[r]))
+                if k + NG < len(stream): issue(k + NG)
+            v, sp2 = self.inv1(Fq, [quad(X, r) for r in range(12)])
+            self.c("---- column %d: accumulator += round(inverse)" % col)
+            tA, tB = V(X + 0, 2), V(X + 2, 2)                   # free again after the inverse
+            if col < 2:
+                for m in range(8):
+                    for half in range(2):
+                        j = m + 8 * half
+                        x = V(v[m].i + 2 * half, 2)
+                        al, ah = V(A[col] + 2 * j), V(A[col] + 2 * j + 1)
+                        self.torus_add(x, al, ah, al, ah, tA, tB)
+            else:
+                # X quad 8 (X+32..35) may hold an output of the inverse (it was the spare): keep clear of it
+                CUR = [V(X + 4 + 2 * j, 2) for j in range(14)] + [V(X + 36, 2), V(X + 38, 2)]
+                for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=8192 + 512 * j)
+                for m in range(8):
+                    for half in range(2):
+                        j = m + 8 * half
+                        x = V(v[m].i + 2 * half, 2)
+                        self.lg_wait(self.regs(CUR[j]))
+                        self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tA, tB)
+                        self.ds_write("ds_write_b64", L8T, CUR[j], offset=8192 + 512 * j)
+        # ---- loop control
+        self.lg_wait_all()
+        e("s_add_u32", SG.ROW.lo(), SG.ROW.lo(), Lit(KP * KP * H * 16))
+        e("s_addc_u32", SG.ROW.hi(), SG.ROW.hi(), Lit(0))
+        e("s_add_u32", SG.I, SG.I, Lit(1))
+        e("s_cmp_lt_u32", SG.I, SG.NSTEP)
+        assert self.vmq == [] and self.lgq == [], (self.vmq, self.lgq)      # same state as at the loop head
+        e("s_cbranch_scc1", "L_step%=")
+
+    def epilogue(self):
+        e = self.e
+        self.c("---- epilogue: store the accumulator")
+        self.vm_wait_all()
+        e("v_add_u32", T0.lo(), Lit(4096), L8)
+        for q in range(3):
+            e("s_add_u32", SG.KP0.lo(), SG.OUT.lo(), Lit(q * 8192))
+            e("s_addc_u32", SG.KP0.hi(), SG.OUT.hi(), Lit(0))
+            for m in range(16):
+                if q < 2: src = V(A[q] + 2 * m, 2)
+                else:
+                    src = V(X + 2 * m, 2)
+                    self.ds_read("ds_read_b64", src, L8T, offset=8192 + 512 * m)
+                    self.lg_wait(self.regs(src))
+                self.gstore("global_store_dwordx2", L8 if m < 8 else T0.lo(), src, SG.KP0, offset=512 * (m & 7))
+        self.vm_wait_all()
+
+    def build(self):
+        self.prologue()
+        self.step()
+        self.epilogue()
+        return self.p
+
+
+INPUTS = ["ct", "row", "out", "n", "tile"]     # asm operands %0..%4 ("s" constraints)
+
+
+def render_inc(prog):
+    """C string literal pieces of ONE asm block.  Operand copies first: %0 ct (64), %1 bsk row 0 (64), %2 out (64), %3 n, %4 tile base"""
+    head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
+            "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE]
+    lines = ["  " + h for h in head] + prog.render()
+    out = ["// generated by tools/asmgen/brgen.py -- do not edit"]
+    for l in lines:
+        out.append('"%s\\n"' % l.replace('"', '\\"'))
+    return "\n".join(out) + "\n"
+
+
+def render_clobbers():
+    regs = ["v%d" % i for i in range(256)] + ["s%d" % i for i in range(34, 68)] + ["vcc", "scc", "memory"]
+    return "// generated by tools/asmgen/brgen.py -- do not edit\n" + ", ".join('"%s"' % r for r in regs) + "\n"
+
+
+if __name__ == "__main__":
+    g = Gen()
+    prog = g.build()
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":
+        import os
+        open(os.path.join(sys.argv[2], "tx_br_asm.inc"), "w").write(render_inc(prog))
+        open(os.path.join(sys.argv[2], "tx_br_asm_clobbers.inc"), "w").write(render_clobbers())
+    elif len(sys.argv) > 1 and sys.argv[1] == "--count":
+        c = prog.count()
+        for k in sorted(c, key=lambda k: -c[k]): print("%6d %s" % (c[k], k))
+        print("%6d total" % sum(c.values()))
+    else:
+        sys.stdout.write(render_inc(prog))

@@ -1,0 +1,387 @@
+"""Tiny gfx950 assembly DSL + lane-exact emulator for the generated blind-rotation loop.
+
+The generator (brgen.py) builds a list of `Ins` objects; `render()` turns them into the text of ONE
+inline-asm block, `Emu` executes them on 64 lanes with numpy so that the instruction stream can be
+checked bit-for-bit against the CPU oracle WITHOUT a GPU.  The emulator also models the two memory
+counters: a load's destination registers are poisoned until an `s_waitcnt` retires the load, and any
+instruction that reads a poisoned register raises -- a missing or too-weak wait is a test failure
+here, not a silent race on the hardware.
+
+Only the instruction subset the generator uses is implemented.  Development tool: not part of the product
+path, not shipped in the library (the generated text is).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------ operands
+class V:
+    """vector register (32-bit) or aligned tuple of `n` registers starting at `i`"""
+    __slots__ = ("i", "n", "neg")
+
+    def __init__(self, i, n=1, neg=False):
+        assert 0 <= i and i + n <= 256, (i, n)
+        if n == 2: assert i % 2 == 0, "64-bit operands must be even-aligned: v%d" % i
+        if n == 4: assert i % 2 == 0, "128-bit tuples must be even-aligned: v%d" % i
+        self.i, self.n, self.neg = i, n, neg
+
+    def __neg__(self): return V(self.i, self.n, not self.neg)
+    def lo(self): return V(self.i)
+    def hi(self): return V(self.i + 1)
+    def sub(self, k, n=2): return V(self.i + k, n)
+
+    def __str__(self):
+        s = "v%d" % self.i if self.n == 1 else "v[%d:%d]" % (self.i, self.i + self.n - 1)
+        return "-" + s if self.neg else s
+
+
+class S:
+    __slots__ = ("i", "n", "neg")
+
+    def __init__(self, i, n=1, neg=False):
+        if n == 2: assert i % 2 == 0
+        self.i, self.n, self.neg = i, n, neg
+
+    def __neg__(self): return S(self.i, self.n, not self.neg)
+    def lo(self): return S(self.i)
+    def hi(self): return S(self.i + 1)
+
+    def __str__(self):
+        s = "s%d" % self.i if self.n == 1 else "s[%d:%d]" % (self.i, self.i + self.n - 1)
+        return "-" + s if self.neg else s
+
+
+class Lit:
+    """32-bit literal / inline constant; `f64` marks an inline double constant (0.0, 1.0, ...)"""
+    __slots__ = ("v", "f64")
+
+    def __init__(self, v, f64=None): self.v, self.f64 = v, f64
+
+    def __str__(self):
+        if self.f64 is not None: return "0" if float(self.f64) == 0.0 else repr(float(self.f64))
+        return str(self.v) if -16 <= self.v <= 64 else hex(self.v & 0xFFFFFFFF)
+
+
+VCC = "vcc"
+
+
+class Ins:
+    __slots__ = ("op", "a", "kw", "cmt")
+
+    def __init__(self, op, *a, **kw):
+        self.cmt = kw.pop("cmt", None)
+        self.op, self.a, self.kw = op, a, kw
+
+    def text(self):
+        if self.op == "label": return "%s:" % self.a[0]
+        if self.op == "comment": return "; %s" % self.a[0]
+        if self.op == "s_waitcnt":
+            parts = []
+            if self.kw.get("vm") is not None: parts.append("vmcnt(%d)" % self.kw["vm"])
+            if self.kw.get("lgkm") is not None: parts.append("lgkmcnt(%d)" % self.kw["lgkm"])
+            return "s_waitcnt " + " ".join(parts)
+        ops = ", ".join(str(x) for x in self.a)
+        mods = ""
+        if "offset" in self.kw and self.kw["offset"]: mods += " offset:%d" % self.kw["offset"]
+        if self.kw.get("off"): ops = ops  # placeholder
+        t = self.op + (" " + ops if ops else "") + mods
+        return t
+
+
+# ------------------------------------------------------------------------------------------ program
+class Prog:
+    def __init__(self):
+        self.ins = []
+
+    def emit(self, op, *a, **kw):
+        self.ins.append(Ins(op, *a, **kw))
+
+    def label(self, name): self.ins.append(Ins("label", name))
+    def comment(self, t): self.ins.append(Ins("comment", t))
+
+    def render(self):
+        out = []
+        for i in self.ins:
+            t = i.text()
+            out.append(t if i.op in ("label",) else "  " + t)
+        return out
+
+    def count(self):
+        c = {}
+        for i in self.ins:
+            if i.op in ("label", "comment"): continue
+            c[i.op] = c.get(i.op, 0) + 1
+        return c
+
+
+# ------------------------------------------------------------------------------------------ emulator
+def _helpers():
+    so = os.path.join(HERE, "_emu_helpers.so")
+    src = os.path.join(HERE, "emu_helpers.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"])
+    L = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.vfma.argtypes = [ctypes.c_int, dp, dp, dp, dp]
+    return L
+
+
+class Poison(Exception):
+    pass
+
+
+class Emu:
+    """one wavefront; LDS is a bytearray shared with whoever set it up; global memory is a dict
+    base address -> numpy uint8 array (addresses are matched by range)"""
+
+    def __init__(self, lds_bytes, globals_):
+        self.v = np.zeros((256, 64), np.uint32)
+        self.pend_v = np.zeros(256, bool)            # destination of an un-retired load
+        self.s = np.zeros(128, np.uint32)
+        self.vcc = np.zeros(64, bool)
+        self.scc = False
+        self.lds = lds_bytes                         # numpy uint8
+        self.g = globals_                            # list of (base, np.uint8 array)
+        self.vmq = []                                # in-flight vector memory ops: (regs, apply_fn)
+        self.lgq = []
+        self.H = _helpers()
+        self.nexec = 0
+        self.stats = {}
+
+    # ---- register access
+    def rd32(self, x):
+        if isinstance(x, V):
+            if self.pend_v[x.i]: raise Poison("read of v%d before its load was waited for" % x.i)
+            return self.v[x.i].copy()
+        if isinstance(x, S): return np.full(64, self.s[x.i], np.uint32)
+        if isinstance(x, Lit): return np.full(64, x.v & 0xFFFFFFFF, np.uint32)
+        raise TypeError(x)
+
+    def rd64(self, x):
+        if isinstance(x, Lit):
+            assert x.f64 is not None
+            r = np.full(64, float(x.f64))
+            return r
+        if isinstance(x, V):
+            assert x.n == 2, x
+            if self.pend_v[x.i] or self.pend_v[x.i + 1]: raise Poison("read of v[%d:%d] before its load was waited for" % (x.i, x.i + 1))
+            bits = self.v[x.i].astype(np.uint64) | (self.v[x.i + 1].astype(np.uint64) << np.uint64(32))
+        else:
+            assert x.n == 2
+            bits = np.full(64, int(self.s[x.i]) | (int(self.s[x.i + 1]) << 32), np.uint64)
+        r = bits.view(np.float64).copy()
+        return -r if x.neg else r
+
+    def wr32(self, d, val):
+        assert isinstance(d, V) and d.n == 1
+        if self.pend_v[d.i]: raise Poison("write to v%d while a load into it is in flight" % d.i)
+        self.v[d.i] = val.astype(np.uint32)
+
+    def wr64(self, d, val):
+        assert isinstance(d, V) and d.n == 2
+        if self.pend_v[d.i] or self.pend_v[d.i + 1]: raise Poison("write to v[%d:%d] while a load into it is in flight" % (d.i, d.i + 1))
+        bits = np.ascontiguousarray(val, np.float64).view(np.uint64)
+        self.v[d.i] = (bits & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        self.v[d.i + 1] = (bits >> np.uint64(32)).astype(np.uint32)
+
+    def fma(self, a, b, c):
+        a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64); c = np.ascontiguousarray(c, np.float64)
+        o = np.empty(64, np.float64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self.H.vfma(64, a.ctypes.data_as(dp), b.ctypes.data_as(dp), c.ctypes.data_as(dp), o.ctypes.data_as(dp))
+        return o
+
+    # ---- memory
+    def gmem(self, addr, nbytes):
+        for base, arr in self.g:
+            if base <= addr and addr + nbytes <= base + arr.size:
+                return arr, addr - base
+        raise IndexError("global access outside every buffer: 0x%x +%d" % (addr, nbytes))
+
+    def retire(self, q, keep):
+        while len(q) > keep:
+            regs, fn = q.pop(0)
+            fn()
+            for r in regs: self.pend_v[r] = False
+
+    # ---- execution
+    def run(self, prog, max_ins=10_000_000):
+        ins = prog.ins
+        labels = {i.a[0]: k for k, i in enumerate(ins) if i.op == "label"}
+        pc = 0
+        while pc < len(ins):
+            i = ins[pc]
+            pc += 1
+            if i.op in ("label", "comment"): continue
+            self.nexec += 1
+            self.stats[i.op] = self.stats.get(i.op, 0) + 1
+            if self.nexec > max_ins: raise RuntimeError("instruction budget exceeded")
+            j = self.step(i)
+            if j is not None: pc = labels[j]
+        # program end: everything must have been waited for
+        if self.vmq or self.lgq: raise Poison("program ended with memory operations in flight")
+
+    def step(self, i):
+        op, a, kw = i.op, i.a, i.kw
+        f = getattr(self, "op_" + op, None)
+        if f is None: raise NotImplementedError(op)
+        return f(*a, **kw)
+
+    # ---- SALU
+    def sval(self, x):
+        if isinstance(x, S): return int(self.s[x.i])
+        if isinstance(x, Lit): return x.v & 0xFFFFFFFF
+        raise TypeError(x)
+
+    def op_s_mov_b32(self, d, a): self.s[d.i] = self.sval(a)
+    def op_s_add_u32(self, d, a, b):
+        r = self.sval(a) + self.sval(b); self.scc = r >> 32 != 0; self.s[d.i] = r & 0xFFFFFFFF
+    def op_s_addc_u32(self, d, a, b):
+        r = self.sval(a) + self.sval(b) + int(self.scc); self.scc = r >> 32 != 0; self.s[d.i] = r & 0xFFFFFFFF
+    def op_s_sub_u32(self, d, a, b):
+        r = self.sval(a) - self.sval(b); self.scc = r < 0; self.s[d.i] = r & 0xFFFFFFFF
+    def op_s_lshr_b32(self, d, a, b): self.s[d.i] = self.sval(a) >> (self.sval(b) & 31)
+    def op_s_lshl_b32(self, d, a, b): self.s[d.i] = (self.sval(a) << (self.sval(b) & 31)) & 0xFFFFFFFF
+    def op_s_and_b32(self, d, a, b): self.s[d.i] = self.sval(a) & self.sval(b)
+    def op_s_cmp_lt_u32(self, a, b): self.scc = self.sval(a) < self.sval(b)
+    def op_s_cbranch_scc1(self, lab): return lab if self.scc else None
+    def op_s_nop(self, n): pass
+
+    def op_s_waitcnt(self, vm=None, lgkm=None):
+        if vm is not None: self.retire(self.vmq, vm)
+        if lgkm is not None: self.retire(self.lgq, lgkm)
+
+    # ---- VALU 32-bit
+    def op_v_mov_b32(self, d, a): self.wr32(d, self.rd32(a))
+    def op_v_xor_b32(self, d, a, b): self.wr32(d, self.rd32(a) ^ self.rd32(b))
+    def op_v_and_b32(self, d, a, b): self.wr32(d, self.rd32(a) & self.rd32(b))
+    def op_v_or_b32(self, d, a, b): self.wr32(d, self.rd32(a) | self.rd32(b))
+    def op_v_add_u32(self, d, a, b): self.wr32(d, self.rd32(a) + self.rd32(b))
+    def op_v_sub_u32(self, d, a, b): self.wr32(d, self.rd32(a) - self.rd32(b))
+    def op_v_subrev_u32(self, d, a, b): self.wr32(d, self.rd32(b) - self.rd32(a))
+    def op_v_lshlrev_b32(self, d, a, b): self.wr32(d, self.rd32(b) << (self.rd32(a) & 31))
+    def op_v_lshrrev_b32(self, d, a, b): self.wr32(d, self.rd32(b) >> (self.rd32(a) & 31))
+    def op_v_lshl_add_u32(self, d, a, b, c): self.wr32(d, (self.rd32(a) << (self.rd32(b) & 31)) + self.rd32(c))
+    def op_v_add3_u32(self, d, a, b, c): self.wr32(d, self.rd32(a) + self.rd32(b) + self.rd32(c))
+
+    def op_v_bfe_u32(self, d, a, off, w):
+        o, wd = int(self.rd32(off)[0]) & 31, int(self.rd32(w)[0]) & 31
+        self.wr32(d, (self.rd32(a) >> o) & np.uint32((1 << wd) - 1))
+
+    def op_v_bfe_i32(self, d, a, off, w):
+        o, wd = int(self.rd32(off)[0]) & 31, int(self.rd32(w)[0]) & 31
+        x = ((self.rd32(a) >> o) & np.uint32((1 << wd) - 1)).astype(np.int64)
+        x = np.where(x >= (1 << (wd - 1)), x - (1 << wd), x)
+        self.wr32(d, x.astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+
+    def op_v_add_co_u32(self, d, vcc, a, b):
+        r = self.rd32(a).astype(np.uint64) + self.rd32(b).astype(np.uint64)
+        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self.vcc = (r >> np.uint64(32)) != 0
+
+    def op_v_addc_co_u32(self, d, vcc, a, b, vin):
+        r = self.rd32(a).astype(np.uint64) + self.rd32(b).astype(np.uint64) + self.vcc.astype(np.uint64)
+        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self.vcc = (r >> np.uint64(32)) != 0
+
+    def op_v_sub_co_u32(self, d, vcc, a, b):
+        x, y = self.rd32(a).astype(np.int64), self.rd32(b).astype(np.int64)
+        r = x - y
+        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self.vcc = r < 0
+
+    def op_v_subb_co_u32(self, d, vcc, a, b, vin):
+        x, y = self.rd32(a).astype(np.int64), self.rd32(b).astype(np.int64)
+        r = x - y - self.vcc.astype(np.int64)
+        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self.vcc = r < 0
+
+    def op_v_mbcnt_lo_u32_b32(self, d, mask, add):
+        m = int(self.rd32(mask)[0])
+        cnt = np.array([bin(m & ((1 << min(l, 32)) - 1)).count("1") for l in range(64)], np.uint32)
+        self.wr32(d, cnt + self.rd32(add))
+
+    def op_v_mbcnt_hi_u32_b32(self, d, mask, add):
+        m = int(self.rd32(mask)[0])
+        cnt = np.array([bin(m & ((1 << max(l - 32, 0)) - 1)).count("1") for l in range(64)], np.uint32)
+        self.wr32(d, cnt + self.rd32(add))
+
+    def op_v_readfirstlane_b32(self, d, a): self.s[d.i] = self.rd32(a)[0]
+
+    # ---- VALU 64-bit float
+    def op_v_mov_b64(self, d, a):
+        self.wr32(V(d.i), self.rd32(V(a.i))); self.wr32(V(d.i + 1), self.rd32(V(a.i + 1)))
+    def op_v_add_f64(self, d, a, b): self.wr64(d, self.rd64(a) + self.rd64(b))
+    def op_v_mul_f64(self, d, a, b): self.wr64(d, self.rd64(a) * self.rd64(b))
+    def op_v_fma_f64(self, d, a, b, c): self.wr64(d, self.fma(self.rd64(a), self.rd64(b), self.rd64(c)))
+    def op_v_rndne_f64(self, d, a): self.wr64(d, np.rint(self.rd64(a)))
+    def op_v_cvt_f64_i32(self, d, a): self.wr64(d, self.rd32(a).view(np.int32).astype(np.float64))
+
+    # ---- LDS (lgkmcnt, in order)
+    def _lds_addr(self, a, offset): return (self.rd32(a).astype(np.int64) + offset)
+
+    def _ds_read(self, d, a, offset, nd):
+        addr = self._lds_addr(a, offset)
+        assert (addr % (4 * min(nd, 2)) == 0).all() or nd == 4, "misaligned LDS read"
+        if nd == 4: assert (addr % 16 == 0).all(), "ds_read_b128 must be 16-byte aligned"
+        assert addr.min() >= 0 and addr.max() + 4 * nd <= self.lds.size, "LDS read out of range: %d..%d" % (addr.min(), addr.max())
+        regs = list(range(d.i, d.i + nd))
+        for r in regs:
+            if self.pend_v[r]: raise Poison("load into v%d while an older load into it is in flight" % r)
+            self.pend_v[r] = True
+
+        def apply(addr=addr, base=d.i, nd=nd):
+            w = self.lds.view(np.uint32)
+            for k in range(nd): self.v[base + k] = w[(addr >> 2) + k]
+        self.lgq.append((regs, apply))
+
+    def op_ds_read_b64(self, d, a, offset=0): self._ds_read(d, a, offset, 2)
+    def op_ds_read_b128(self, d, a, offset=0): self._ds_read(d, a, offset, 4)
+
+    def _ds_write(self, a, src, offset, nd):
+        addr = self._lds_addr(a, offset)
+        if nd == 4: assert (addr % 16 == 0).all(), "ds_write_b128 must be 16-byte aligned"
+        assert (addr % 8 == 0).all()
+        assert addr.min() >= 0 and addr.max() + 4 * nd <= self.lds.size, "LDS write out of range"
+        vals = [self.rd32(V(src.i + k)) for k in range(nd)]           # data is read at issue
+
+        def apply(addr=addr, vals=vals):
+            w = self.lds.view(np.uint32)
+            for k, x in enumerate(vals): w[(addr >> 2) + k] = x
+        self.lgq.append(([], apply))
+
+    def op_ds_write_b64(self, a, src, offset=0): self._ds_write(a, src, offset, 2)
+    def op_ds_write_b128(self, a, src, offset=0): self._ds_write(a, src, offset, 4)
+
+    # ---- global (vmcnt, in order); saddr form: base in an SGPR pair + 32-bit VGPR offset + immediate
+    def _gaddr(self, voff, sbase, offset):
+        base = int(self.s[sbase.i]) | (int(self.s[sbase.i + 1]) << 32)
+        return base + self.rd32(voff).astype(np.int64) + offset
+
+    def _gload(self, d, voff, sbase, offset, nd):
+        assert -4096 <= offset <= 4095, "global immediate offset is 13-bit signed"
+        addr = self._gaddr(voff, sbase, offset)
+        regs = list(range(d.i, d.i + nd))
+        for r in regs:
+            if self.pend_v[r]: raise Poison("load into v%d while an older load into it is in flight" % r)
+            self.pend_v[r] = True
+
+        def apply(addr=addr, base=d.i, nd=nd):
+            for l in range(64):
+                arr, o = self.gmem(int(addr[l]), 4 * nd)
+                self.v[base:base + nd, l] = arr[o:o + 4 * nd].view(np.uint32)
+        self.vmq.append((regs, apply))
+
+    def op_global_load_dwordx4(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 4)
+    def op_global_load_dwordx2(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 2)
+
+    def op_global_store_dwordx2(self, voff, src, sbase, offset=0):
+        assert -4096 <= offset <= 4095
+        addr = self._gaddr(voff, sbase, offset)
+        vals = [self.rd32(V(src.i + k)) for k in range(2)]
+
+        def apply(addr=addr, vals=vals):
+            for l in range(64):
+                arr, o = self.gmem(int(addr[l]), 8)
+                arr[o:o + 8].view(np.uint32)[:] = [vals[0][l], vals[1][l]]
+        self.vmq.append(([], apply))
