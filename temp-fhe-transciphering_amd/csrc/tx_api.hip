@@ -36,9 +36,8 @@ struct tx_ctx {
     cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
     size_t auto_split_stride = 0;
     cplx *tw = nullptr, *tw256 = nullptr;
-    unsigned int *unit_counter = nullptr;   // work counter of the persistent blind rotation
     int num_cus = 0;
-    int br_variant = 0;
+    int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4 forces a kernel
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
     // workspace (grown on demand)
@@ -123,12 +122,13 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipMalloc(&c->unit_counter, 64) != hipSuccess ||
+#ifdef TXD_WITH_BR3
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess ||
+#endif
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess) {
-        fail("tx_create: cannot set up the persistent blind rotation"); delete c; return nullptr;
+        fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); delete c; return nullptr;
     }
     c->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("TX_BR_VARIANT")) c->br_variant = atoi(e);
@@ -150,7 +150,7 @@ extern "C" void tx_destroy(tx_ctx *c)
     hipStreamSynchronize(c->stream);
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
-    hipFree(c->tw); hipFree(c->unit_counter); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
+    hipFree(c->tw); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     hipStreamDestroy(c->stream);
     delete c;
@@ -325,12 +325,19 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
-    if (c->br_variant == 4) {
+    // Two kernels, same results bit for bit.  k_blind_rotate4 (generated assembly, two waves per SIMD, two 256-thread
+    // workgroups per CU) wins once every SIMD can hold two units: more than 4 units per CU.  Below that a launch is one
+    // wave per SIMD anyway and k_blind_rotate (three transforms interleaved in 512 registers) is the faster one
+    // (1024 units: 8.0 against 8.5 ms; 8192 units: 59.7 against 47.6 ms).
+    const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 4 : 0);
+    if (variant == 4) {
         hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
                            (int)c->p.n, c->bsk_f, c->tw);
-    } else if (c->br_variant == 3) {
+#ifdef TXD_WITH_BR3
+    } else if (variant == 3) {
         hipLaunchKernelGGL(k_blind_rotate3, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
                            (int)c->p.n, c->bsk_f, c->tw);
+#endif
     } else
     hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
                        (int)c->p.n, c->bsk_f, c->tw);

@@ -37,6 +37,7 @@ constexpr size_t BR3_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)N * sizeof(
 constexpr size_t LDS_BYTES_BR3 = BR3_TW_CPLX * sizeof(cplx) + WAVES * BR3_WAVE_BYTES;
 static_assert(LDS_BYTES_BR3 <= 80 * 1024, "two workgroups per CU");
 
+#ifdef TXD_WITH_BR3   // the hipcc version of this layout: readable specification of the generated loop, not built by default
 struct Br3Ctx {
     const cplx *tw;     // twist rows 0..7, pass-A rows 8..14 (row 7 + r), pass-B compact at BR3_TWB
     cplx *tile;         // 512 complex, unpadded
@@ -300,6 +301,8 @@ void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     }
 }
 
+#endif  // TXD_WITH_BR3
+
 // ------------------------------------------------------------------------------------------
 // k_blind_rotate4: the same kernel with the CMux loop as generated assembly (tools/asmgen/brgen.py ->
 // tx_br_asm.inc): fixed register map (256 VGPRs, nothing in scratch), counted waits, key ring of 12 complex
@@ -334,6 +337,17 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     }
     const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
     uint64_t *out = acc_out + (size_t)unit * GL;
+#ifdef TXD_STAMPS   // diagnostic build: per-phase cycle sums of one wave (tools/br_only.py); every other wave writes to a sink
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps + 8;
+    if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
+    asm volatile(
+#include "tx_br_asm_stamps.inc"
+        :
+        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(dbg)
+        :
+#include "tx_br_asm_clobbers.inc"
+    );
+#else
     asm volatile(
 #include "tx_br_asm.inc"
         :
@@ -341,6 +355,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
         :
 #include "tx_br_asm_clobbers.inc"
     );
+#endif
 }
 
 }  // namespace txd

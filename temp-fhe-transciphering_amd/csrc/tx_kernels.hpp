@@ -29,7 +29,10 @@ __device__ unsigned long long txd_stamps[16];                   // read back by 
 #ifndef TXD_STAMP_THREAD
 #define TXD_STAMP_THREAD 0
 #endif
-#define TXD_STAMP_FLUSH(steps) do { if (blockIdx.x == 64 && threadIdx.x == TXD_STAMP_THREAD) { for (int q = 0; q < 6; q++) txd_stamps[q] = st_acc[q]; \
+#ifndef TXD_STAMP_BLOCK
+#define TXD_STAMP_BLOCK 64
+#endif
+#define TXD_STAMP_FLUSH(steps) do { if (blockIdx.x == TXD_STAMP_BLOCK && threadIdx.x == TXD_STAMP_THREAD) { for (int q = 0; q < 6; q++) txd_stamps[q] = st_acc[q]; \
                                     txd_stamps[6] = (unsigned long long)(steps); for (int q = 0; q < 4; q++) txd_stamps[8 + q] = fst.acc[q]; } } while (0)
 #else
 #define TXD_STAMP_DECL() do {} while (0)

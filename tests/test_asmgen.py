@@ -1,0 +1,41 @@
+"""CPU tests of the generated-assembly CMux loop (tools/asmgen): the emitted instruction stream, executed in the
+lane-exact emulator, equals a reference built from the oracle's primitives bit for bit (the emulator also fails on
+any register read before its load was waited for), and the files under csrc/ are what the generator emits now."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "asmgen")
+CSRC = os.path.join(ROOT, "temp-fhe-transciphering_amd", "csrc")
+
+
+def test_generated_loop_equals_oracle_in_the_emulator(oracle):
+    for steps, seed in ((3, 1), (2, 77)):
+        r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu.py"), str(steps), str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+def test_stamped_variant_is_the_same_arithmetic(oracle):
+    env = dict(os.environ, BR_STAMPS="1")
+    r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+def test_committed_assembly_is_current(tmp_path):
+    subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
+    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_clobbers.inc"):
+        assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
+
+
+def test_register_budget_and_no_scratch():
+    """the loop must fit 256 VGPRs with nothing in scratch: two waves per SIMD is the whole point"""
+    sys.path.insert(0, GEN)
+    import brgen, gcn
+    prog = brgen.Gen().build()
+    top = 0
+    for i in prog.ins:
+        for x in i.a:
+            if isinstance(x, gcn.V): top = max(top, x.i + x.n)
+    assert top <= 256
+    assert not any(i.op.startswith("scratch_") for i in prog.ins)

@@ -370,3 +370,41 @@ def test_trace_and_scheme_switch_ring_stress(rig256):
     for rep in range(2):
         assert np.array_equal(eng.scheme_switch_fourier(glev), f_o)
     assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
+
+
+@pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
+def test_two_wave_blind_rotation_kernel_bit_identical(which, request, monkeypatch):
+    """k_blind_rotate4 (generated assembly, csrc/tx_br_asm.inc) forced on a small launch: equals the oracle"""
+    import txhip
+    r = request.getfixturevalue(which)
+    rng = np.random.default_rng(17)
+    lwe = rng.integers(0, 1 << 63, (13, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (13, r.p.n + 1), dtype=np.uint64)
+    lwe[0, 5] = 0                               # rotation by 0
+    lwe[1, r.p.n] = np.uint64(2**64 - 1)        # body at the wrap-around
+    lwe[2, :] = 0
+    ref = r.octx.blind_rotate(lwe)
+    monkeypatch.setenv("TX_BR_VARIANT", "4")
+    e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)      # 13 units: a ragged last workgroup
+    e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    got = e4.blind_rotate(lwe)
+    e4.close()
+    assert np.array_equal(got, ref)
+
+
+def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):
+    """more than four units per CU: the two-wave kernel runs by itself; same bits as the one-wave kernel on every
+    unit, and as the oracle on a sample"""
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(23)
+    cnt = 4 * 256 + 4 * 37 + 3                  # > 4 units per CU on a 256-CU chip, ragged
+    lwe = rng.integers(0, 1 << 63, (cnt, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.p.n + 1), dtype=np.uint64)
+    auto = r.eng.blind_rotate(lwe)
+    monkeypatch.setenv("TX_BR_VARIANT", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    one_wave = e0.blind_rotate(lwe)
+    e0.close()
+    assert np.array_equal(auto, one_wave)
+    pick = np.r_[0:6, cnt - 6:cnt]
+    assert np.array_equal(auto[pick], r.octx.blind_rotate(lwe[pick]))

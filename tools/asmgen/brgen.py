@@ -63,15 +63,62 @@ class Cx:
     def mul_mi(self): return Cx(self.im, -self.re, self.q)        # * -i
 
 
+CARRY = [S(88, 2), S(90, 2), S(92, 2), S(94, 2)]      # one carry mask per interleaved integer chain (VOP3 carry operands)
+NSTAMP = 6
+ST_ACC = [S(70 + 2 * k, 2) for k in range(NSTAMP)]
+ST_PREV, ST_NOW, ST_DBG = S(82, 2), S(84, 2), S(86, 2)
+
+
 class Gen:
-    def __init__(self):
+    def __init__(self, stamps=False):
+        self.stamps = stamps
         self.p = Prog()
+        self.buf = None
         self.vmq = []          # in-flight vector-memory ops, oldest first: sets of destination registers
         self.lgq = []
 
     # ---------------------------------------------------------------- emission + counters
-    def e(self, op, *a, **kw): self.p.emit(op, *a, **kw)
-    def c(self, t): self.p.comment(t)
+    # Every emitted instruction goes through e(): registers it touches that are the destination of a load still in
+    # flight get the (counted) wait in front of it, and loads / stores are entered in the two in-order queues.  So
+    # waits always sit as late as the program order allows, and reordering the emission can never lose one.
+    def e(self, op, *a, **kw):
+        if self.buf is not None:
+            self.buf.append((op, a, kw)); return
+        if op not in ("s_waitcnt", "label", "comment"):
+            touched = set()
+            for x in a:
+                if isinstance(x, V): touched |= self.regs(x)
+            if touched:
+                k = self._wait(self.vmq, touched, 63)
+                if k is not None: self.p.emit("s_waitcnt", vm=k)
+                k = self._wait(self.lgq, touched, 15)
+                if k is not None: self.p.emit("s_waitcnt", lgkm=k)
+        self.p.emit(op, *a, **kw)
+        if op.startswith("ds_read"): self.lgq.append(self.regs(a[0]))
+        elif op.startswith("ds_write"): self.lgq.append(set())
+        elif op == "s_memtime": self.lgq.append(set())
+        elif op.startswith("global_load"): self.vmq.append(self.regs(a[0]))
+        elif op.startswith("global_store"): self.vmq.append(set())
+
+    def c(self, t):
+        if self.buf is None: self.p.comment(t)
+
+    def chain(self, fn, *args):
+        """record the instructions fn(*args) emits, without processing them"""
+        assert self.buf is None
+        self.buf = []
+        fn(*args)
+        b, self.buf = self.buf, None
+        return b
+
+    def merge(self, chains):
+        """emit independent instruction chains round-robin (in-order issue: the neighbours cover each other's latency)"""
+        chains = [list(c) for c in chains if c]
+        while chains:
+            for c in list(chains):
+                op, a, kw = c.pop(0)
+                self.e(op, *a, **kw)
+                if not c: chains.remove(c)
 
     def _wait(self, q, regs, limit):
         regs = set(regs)
@@ -83,36 +130,39 @@ class Gen:
         del q[:len(q) - keep]
         return keep
 
-    def vm_wait(self, regs):
-        k = self._wait(self.vmq, regs, 63)
-        if k is not None: self.e("s_waitcnt", vm=k)
-
-    def lg_wait(self, regs):
-        k = self._wait(self.lgq, regs, 15)
-        if k is not None: self.e("s_waitcnt", lgkm=k)
+    def vm_wait(self, regs): pass        # kept for call sites: e() places every wait
+    def lg_wait(self, regs): pass
 
     def lg_wait_all(self):
         if self.lgq:
-            self.e("s_waitcnt", lgkm=0); self.lgq.clear()
+            self.p.emit("s_waitcnt", lgkm=0); self.lgq.clear()
 
     def vm_wait_all(self):
         if self.vmq:
-            self.e("s_waitcnt", vm=0); self.vmq.clear()
+            self.p.emit("s_waitcnt", vm=0); self.vmq.clear()
 
     @staticmethod
     def regs(v): return set(range(v.i, v.i + v.n))
 
-    def ds_read(self, op, d, addr, offset=0):
-        self.e(op, d, addr, offset=offset); self.lgq.append(self.regs(d))
+    def ds_read(self, op, d, addr, offset=0): self.e(op, d, addr, offset=offset)
+    def ds_write(self, op, addr, src, offset=0): self.e(op, addr, src, offset=offset)
+    def gload(self, op, d, voff, sbase, offset=0): self.e(op, d, voff, sbase, offset=offset)
+    def gstore(self, op, voff, src, sbase, offset=0): self.e(op, voff, src, sbase, offset=offset)
 
-    def ds_write(self, op, addr, src, offset=0):
-        self.e(op, addr, src, offset=offset); self.lgq.append(set())
-
-    def gload(self, op, d, voff, sbase, offset=0):
-        self.e(op, d, voff, sbase, offset=offset); self.vmq.append(self.regs(d))
-
-    def gstore(self, op, voff, src, sbase, offset=0):
-        self.e(op, voff, src, sbase, offset=offset); self.vmq.append(set())
+    def stamp(self, k):
+        """diagnostic build only: cycles since the previous stamp are added to accumulator k (s_memtime returns
+        through lgkmcnt, so the LDS queue is drained first: the stamps perturb what they measure)"""
+        if not self.stamps: return
+        self.lg_wait_all()
+        self.e("s_memtime", ST_NOW)
+        self.lg_wait_all()
+        if k is not None:
+            self.e("s_sub_u32", SG.TMP, ST_NOW.lo(), ST_PREV.lo())
+            self.e("s_subb_u32", SG.TMP2, ST_NOW.hi(), ST_PREV.hi())
+            self.e("s_add_u32", ST_ACC[k].lo(), ST_ACC[k].lo(), SG.TMP)
+            self.e("s_addc_u32", ST_ACC[k].hi(), ST_ACC[k].hi(), SG.TMP2)
+        self.e("s_mov_b32", ST_PREV.lo(), ST_NOW.lo())
+        self.e("s_mov_b32", ST_PREV.hi(), ST_NOW.hi())
 
     # ---------------------------------------------------------------- complex helpers (bit-exact op order)
     def cadd_to(self, dst, x, y):      # dst = x + y   (dst quad; x, y views)
@@ -144,6 +194,17 @@ class Gen:
         self.e("v_mul_f64", tmp2, x, wy)
         self.e("v_fma_f64", y, y, wx, -tmp2)
         self.e("v_fma_f64", x, x, wx, tmp)
+
+    def cmul_all(self, pairs, spare=None, conj=False):
+        """q *= w (or conj(w)) for a list of (q, w); two chains in flight (temporaries: T0, T1; for the conjugate
+        form, which needs two each, also the two halves of the free quad `spare`)"""
+        tA = (T0, T1) if conj else (T0,)
+        tB = (qre(spare), qim(spare)) if conj else (T1,)
+        fn = self.cmulc if conj else self.cmul
+        for k in range(0, len(pairs), 2):
+            chains = [self.chain(fn, pairs[k][0], pairs[k][1], *tA)]
+            if k + 1 < len(pairs): chains.append(self.chain(fn, pairs[k + 1][0], pairs[k + 1][1], *tB))
+            self.merge(chains)
 
     def dft8(self, v, spare, sign):
         """8-point DFT of the complex values in quads v[0..7] (dft8<sign> of tx_device.hpp, same pairing).
@@ -233,23 +294,19 @@ class Gen:
             else: self.ds_read("ds_read_b128", dst[k], L16, offset=1024 * (row0 + k))
 
     # ---------------------------------------------------------------- forward transforms, three polynomials together
-    def fwd3(self, polys, xq):
+    def fwd3(self, polys, xq, before_pass3=None):
         """polys: three lists of 8 quads (digits as doubles); xq: 12 free quads of region X.
         On return polys[p][r] is the quad holding F-layout register r of polynomial p."""
         tw, spare = xq[:8], xq[8]
         self.c("forward x3: twist")
         self.load_tw(tw, 0, 8)
         for p in range(3):
-            for m in range(8):
-                self.lg_wait(self.regs(tw[m]))
-                self.cmul(polys[p][m], tw[m], T0)
+            self.cmul_all([(polys[p][m], tw[m]) for m in range(8)])
         self.c("forward x3: pass 1 (dft8, pass-A twiddles, exchange hi)")
         self.load_tw(tw, 8, 7)
         for p in range(3):
             polys[p], spare = self.dft8(polys[p], spare, +1)
-            for r in range(1, 8):
-                self.lg_wait(self.regs(tw[r - 1]))
-                self.cmul(polys[p][r], tw[r - 1], T0)
+            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)])
             self.xchg_hi_write(polys[p])
             # the stores captured their data: the eight quads + the spare are free; read back into a canonical set
             free = sorted(polys[p] + [spare], key=lambda q: q.i)
@@ -260,14 +317,13 @@ class Gen:
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
             polys[p], spare = self.dft8(polys[p], spare, +1)
-            for r in range(1, 8):
-                self.lg_wait(self.regs(tw[r - 1]))
-                self.cmul(polys[p][r], tw[r - 1], T0)
+            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)])
             self.xchg_lo_write(polys[p])
             free = sorted(polys[p] + [spare], key=lambda q: q.i)
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=True)
         self.c("forward x3: pass 3 (dft8)")
+        if before_pass3: before_pass3()            # the twiddle quads xq[0..7] are free from here on
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
             polys[p], spare = self.dft8(polys[p], spare, +1)
@@ -286,9 +342,7 @@ class Gen:
         self.xchg_read(v, swz=True)
         self.lg_wait(set().union(*[self.regs(q) for q in v]))
         self.c("inverse: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
-        for r in range(1, 8):
-            self.lg_wait(self.regs(tw[r - 1]))
-            self.cmulc(v[r], tw[r - 1], T0, T1)
+        self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
         self.load_tw(tw, 8, 7)
         v, spare = self.dft8(v, spare, -1)
         self.xchg_hi_write(v)
@@ -297,28 +351,24 @@ class Gen:
         self.xchg_read(v, swz=False)
         self.lg_wait(set().union(*[self.regs(q) for q in v]))
         self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist)")
-        for r in range(1, 8):
-            self.lg_wait(self.regs(tw[r - 1]))
-            self.cmulc(v[r], tw[r - 1], T0, T1)
+        self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
         self.load_tw(tw, 0, 8)
         v, spare = self.dft8(v, spare, -1)
         v, spare = self.home(v, spare, F, F + 32)
-        for m in range(8):
-            self.lg_wait(self.regs(tw[m]))
-            self.cmulc(v[m], tw[m], T0, T1)
+        self.cmul_all([(v[m], tw[m]) for m in range(8)], spare, conj=True)
         return v, spare
 
     # ---------------------------------------------------------------- integer <-> double
-    def digit_pair(self, q, own_lo, own_hi, sgn):
+    def digit_pair(self, q, own_lo, own_hi, sgn, t, cy=VCC):
         """q holds a rotated torus word in (q.i, q.i+1): replace it by the f64 digit of (+-word - own).
         pbs_digit of tx_kernels.hpp (B = 23, one level, balanced top tie)."""
-        lo, hi, t = V(q.i), V(q.i + 1), T0.lo()
+        lo, hi = V(q.i), V(q.i + 1)
         self.e("v_xor_b32", lo, lo, sgn)
         self.e("v_xor_b32", hi, hi, sgn)
-        self.e("v_sub_co_u32", lo, VCC, lo, sgn)
-        self.e("v_subb_co_u32", hi, VCC, hi, sgn, VCC)
-        self.e("v_sub_co_u32", lo, VCC, lo, own_lo)
-        self.e("v_subb_co_u32", hi, VCC, hi, own_hi, VCC)
+        self.e("v_sub_co_u32", lo, cy, lo, sgn)
+        self.e("v_subb_co_u32", hi, cy, hi, sgn, cy)
+        self.e("v_sub_co_u32", lo, cy, lo, own_lo)
+        self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
         self.e("v_add_u32", t, Lit(0x100), hi)
         self.e("v_bfe_u32", t, t, Lit(9), Lit(23))
         self.e("v_sub_u32", t, t, EREG)
@@ -326,7 +376,7 @@ class Gen:
         self.e("v_add_u32", t, t, EREG)
         self.e("v_cvt_f64_i32", V(q.i, 2), t)
 
-    def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB):
+    def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB, cy=VCC):
         """dst = cur + round-half-even(x) mod 2^64 (torus_add_f64 of tx_device.hpp); x: f64 pair (destroyed);
         tA, tB: temporary pairs"""
         self.e("v_mul_f64", tA, x, SG.C_2M64)
@@ -337,14 +387,14 @@ class Gen:
         self.e("v_add_f64", x, x, -tB)                         # lo
         self.e("v_add_f64", x, x, SG.C_52)                     # t2
         self.e("v_add3_u32", tA.lo(), tA.lo(), x.hi(), SG.C_M4338)     # rhi = bits(t1).lo + bits(t2).hi - 0x43380000
-        self.e("v_add_co_u32", dst_lo, VCC, cur_lo, x.lo())
-        self.e("v_addc_co_u32", dst_hi, VCC, cur_hi, tA.lo(), VCC)
+        self.e("v_add_co_u32", dst_lo, cy, cur_lo, x.lo())
+        self.e("v_addc_co_u32", dst_hi, cy, cur_hi, tA.lo(), cy)
 
     # ---------------------------------------------------------------- the kernel
     def prologue(self):
         e = self.e
         self.c("---- prologue: lane-dependent addresses, constants, accumulator mask = 0")
-        e("s_waitcnt", vm=0, lgkm=0)
+        self.p.emit("s_waitcnt", vm=0, lgkm=0)
         e("v_mbcnt_lo_u32_b32", LANE, Lit(-1), Lit(0))
         e("v_mbcnt_hi_u32_b32", LANE, Lit(-1), LANE)
         e("v_lshl_add_u32", L8T, LANE, Lit(3), SG.TILE)
@@ -375,6 +425,10 @@ class Gen:
         e("v_mov_b32", R10, Lit(0))
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0 (voffset register = its own dst: read at issue)
         e("s_mov_b32", SG.I, Lit(0))
+        if self.stamps:
+            for k in range(NSTAMP):
+                e("s_mov_b32", ST_ACC[k].lo(), Lit(0)); e("s_mov_b32", ST_ACC[k].hi(), Lit(0))
+            self.stamp(None)
 
     def step(self):
         e = self.e
@@ -384,7 +438,7 @@ class Gen:
         # loop head: the only vector-memory operation that can be in flight is the load of this step's mask element
         # (from the prologue on entry; on the back edge it retired behind the key loads).  A full wait makes both
         # entries the same state.
-        self.e("s_waitcnt", vm=0); self.vmq.clear()
+        self.p.emit("s_waitcnt", vm=0); self.vmq.clear()
         e("v_readfirstlane_b32", SG.CTV.hi(), R11)
         e("s_nop", Lit(3))
         e("s_lshr_b32", SG.TMP, SG.CTV.hi(), Lit(23))           # x >> 55
@@ -415,80 +469,108 @@ class Gen:
         # ---- stage the mask polynomials through the tile, gather the rotated words (in-order LDS: no waits in between)
         self.c("---- rotation: stage mask polynomials in the tile, gather rotated coefficients")
         xq = [quad(X, r) for r in range(12)]
-        for q in range(2):
-            for m in range(16): self.ds_write("ds_write_b64", L8T, V(A[q] + 2 * m, 2), offset=512 * m)
-            for m in range(8):
-                self.ds_read("ds_read_b64", V(D[q] + 4 * m, 2), RA[m], offset=0)
-                self.ds_read("ds_read_b64", V(D[q] + 4 * m + 2, 2), RA[m + 8], offset=0)
         OWN = [V(X + 2 * j, 2) for j in range(16)]              # body words of this lane
-        for j in range(16): self.ds_read("ds_read_b64", OWN[j], L8T, offset=8192 + 512 * j)
-        for m in range(8):
-            self.ds_read("ds_read_b64", V(D[2] + 4 * m, 2), RA[m], offset=8192)
-            self.ds_read("ds_read_b64", V(D[2] + 4 * m + 2, 2), RA[m + 8], offset=8192)
-        self.c("---- digits: ct1 = acc X^rot - acc, one level (B = 23), as f64")
-        for q in range(3):
+        temps = [T0.lo(), T0.hi(), T1.lo(), T1.hi()]
+
+        def lds_traffic(q):
+            if q < 2:
+                for m in range(16): self.ds_write("ds_write_b64", L8T, V(A[q] + 2 * m, 2), offset=512 * m)
+            else:
+                for j in range(16): self.ds_read("ds_read_b64", OWN[j], L8T, offset=8192 + 512 * j)
+            for m in range(8):
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m, 2), RA[m], offset=8192 if q == 2 else 0)
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m + 2, 2), RA[m + 8], offset=8192 if q == 2 else 0)
+
+        def digits(q):
+            chains = []
             for m in range(8):
                 for half in range(2):
                     j = m + 8 * half
                     slot = V(D[q] + 4 * m + 2 * half, 2)
-                    self.lg_wait(self.regs(slot))
                     if q < 2: ol, oh = V(A[q] + 2 * j), V(A[q] + 2 * j + 1)
-                    else:
-                        self.lg_wait(self.regs(OWN[j]))
-                        ol, oh = OWN[j].lo(), OWN[j].hi()
-                    self.digit_pair(slot, ol, oh, SGN[j])
+                    else: ol, oh = OWN[j].lo(), OWN[j].hi()
+                    chains.append(self.chain(self.digit_pair, slot, ol, oh, SGN[j], temps[len(chains) % 4], CARRY[len(chains) % 4]))
+                    if len(chains) == 4:
+                        self.merge(chains); chains = []
+        lds_traffic(0)
+        lds_traffic(1)                  # in-order LDS: polynomial 1's stores queue behind polynomial 0's gathers
+        self.c("---- digits: ct1 = acc X^rot - acc, one level (B = 23), as f64")
+        digits(0)
+        lds_traffic(2)
+        digits(1)
+        digits(2)
+        self.stamp(0)
         # ---- forward transforms
+        NG, EARLY = 12, 8
+        stream = [(q, r) for q in range(3) for r in range(8)]
+        kps = (SG.KP0, SG.KP1, SG.KP2)
+
+        def ring_of(col):      # the first EARLY slots are the quads that are free when they are issued
+            order = list(range(12)) if col == 0 else list(range(4, 12)) + list(range(4))
+            return [quad(X, r) for r in order]
+
+        def key_ptrs(col):
+            for q in range(3):
+                e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
+                e("s_addc_u32", kps[q].hi(), SG.ROW.hi(), Lit(0))
+
+        def issue(col, k):
+            q, r = stream[k]
+            self.gload("global_load_dwordx4", ring_of(col)[k % NG], L16 if r < 4 else OFF1, kps[q], offset=(r & 3) * 1024)
+
+        def early(col):
+            self.c("key ring: first %d elements of column %d, issued ahead of their use" % (EARLY, col))
+            key_ptrs(col)
+            for k in range(EARLY): issue(col, k)
         polys = [[quad(D[p], r) for r in range(8)] for p in range(3)]
-        polys, spare = self.fwd3(polys, xq)
+        polys, spare = self.fwd3(polys, xq, before_pass3=lambda: early(0))
+        self.stamp(1)
         # ---- per column: multiply-accumulate against the key, inverse transform, update
         for col in range(3):
             self.c("---- column %d: F = sum_q D_q * key[q][col]" % col)
-            for q in range(3):
-                kp = (SG.KP0, SG.KP1, SG.KP2)[q]
-                e("s_add_u32", kp.lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
-                e("s_addc_u32", kp.hi(), SG.ROW.hi(), Lit(0))
-            NG = 12
-            ring = [quad(X, r) for r in range(NG)]
-            stream = [(q, r) for q in range(3) for r in range(8)]
-
-            def issue(k):
-                q, r = stream[k]
-                kp = (SG.KP0, SG.KP1, SG.KP2)[q]
-                self.gload("global_load_dwordx4", ring[k % NG], L16 if r < 4 else OFF1, kp, offset=(r & 3) * 1024)
-            for k in range(NG): issue(k)
+            ring = ring_of(col)
+            for k in range(EARLY, NG): issue(col, k)
             Fq = [quad(F, r) for r in range(8)]
-            for k, (q, r) in enumerate(stream):
-                g = ring[k % NG]
-                self.vm_wait(self.regs(g))
-                d = polys[q][r]
+
+            def mac(k):
+                q, r = stream[k]
+                g, d = ring[k % NG], polys[q][r]
                 re0 = Lit(0, f64=0.0) if q == 0 else qre(Fq[r])
                 im0 = Lit(0, f64=0.0) if q == 0 else qim(Fq[r])
-                e("v_fma_f64", qre(Fq[r]), qre(d), qre(g), re0)
-                e("v_fma_f64", qre(Fq[r]), -qim(d), qim(g), qre(Fq[r]))
-                e("v_fma_f64", qim(Fq[r]), qre(d), qim(g), im0)
-                e("v_fma_f64", qim(Fq[r]), qim(d), qre(g), qim(Fq[r]))
-                if k + NG < len(stream): issue(k + NG)
+                self.e("v_fma_f64", qre(Fq[r]), qre(d), qre(g), re0)
+                self.e("v_fma_f64", qim(Fq[r]), qre(d), qim(g), im0)
+                self.e("v_fma_f64", qre(Fq[r]), -qim(d), qim(g), qre(Fq[r]))
+                self.e("v_fma_f64", qim(Fq[r]), qim(d), qre(g), qim(Fq[r]))
+            for k in range(0, len(stream), 2):
+                self.merge([self.chain(mac, k), self.chain(mac, k + 1)])
+                for kk in (k, k + 1):
+                    if kk + NG < len(stream): issue(col, kk + NG)
+            self.stamp(2)
             v, sp2 = self.inv1(Fq, [quad(X, r) for r in range(12)])
+            self.stamp(3)
+            if col < 2: early(col + 1)              # lands during the conversions below (they use X[0..3] only)
             self.c("---- column %d: accumulator += round(inverse)" % col)
-            tA, tB = V(X + 0, 2), V(X + 2, 2)                   # free again after the inverse
-            if col < 2:
-                for m in range(8):
-                    for half in range(2):
-                        j = m + 8 * half
-                        x = V(v[m].i + 2 * half, 2)
-                        al, ah = V(A[col] + 2 * j), V(A[col] + 2 * j + 1)
-                        self.torus_add(x, al, ah, al, ah, tA, tB)
-            else:
-                # X quad 8 (X+32..35) may hold an output of the inverse (it was the spare): keep clear of it
-                CUR = [V(X + 4 + 2 * j, 2) for j in range(14)] + [V(X + 36, 2), V(X + 38, 2)]
+            tmp = [(V(X + 4 * k, 2), V(X + 4 * k + 2, 2)) for k in range(4)]     # X[0..3]: free again after the inverse
+            CUR = [V(X + 16 + 2 * j, 2) for j in range(16)]                      # body words (column 2): X[4..11]
+            if col == 2:
                 for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=8192 + 512 * j)
-                for m in range(8):
-                    for half in range(2):
-                        j = m + 8 * half
-                        x = V(v[m].i + 2 * half, 2)
-                        self.lg_wait(self.regs(CUR[j]))
-                        self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tA, tB)
-                        self.ds_write("ds_write_b64", L8T, CUR[j], offset=8192 + 512 * j)
+
+            def upd(m, half, k):
+                j = m + 8 * half
+                x = V(v[m].i + 2 * half, 2)
+                if col < 2:
+                    al, ah = V(A[col] + 2 * j), V(A[col] + 2 * j + 1)
+                    self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k])
+                else:
+                    self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tmp[k][0], tmp[k][1], CARRY[k])
+                    self.ds_write("ds_write_b64", L8T, CUR[j], offset=8192 + 512 * j)
+            chains = []
+            for m in range(8):
+                for half in range(2):
+                    chains.append(self.chain(upd, m, half, len(chains)))
+                    if len(chains) == 4:
+                        self.merge(chains); chains = []
+            self.stamp(4)
         # ---- loop control
         self.lg_wait_all()
         e("s_add_u32", SG.ROW.lo(), SG.ROW.lo(), Lit(KP * KP * H * 16))
@@ -514,6 +596,12 @@ class Gen:
                     self.lg_wait(self.regs(src))
                 self.gstore("global_store_dwordx2", L8 if m < 8 else T0.lo(), src, SG.KP0, offset=512 * (m & 7))
         self.vm_wait_all()
+        if self.stamps:
+            e("v_mov_b32", T0.hi(), Lit(0))
+            for k in range(NSTAMP):
+                e("v_mov_b32", T1.lo(), ST_ACC[k].lo()); e("v_mov_b32", T1.hi(), ST_ACC[k].hi())
+                self.gstore("global_store_dwordx2", T0.hi(), T1, ST_DBG, offset=8 * k)
+            self.vm_wait_all()
 
     def build(self):
         self.prologue()
@@ -525,10 +613,11 @@ class Gen:
 INPUTS = ["ct", "row", "out", "n", "tile"]     # asm operands %0..%4 ("s" constraints)
 
 
-def render_inc(prog):
+def render_inc(prog, stamps=False):
     """C string literal pieces of ONE asm block.  Operand copies first: %0 ct (64), %1 bsk row 0 (64), %2 out (64), %3 n, %4 tile base"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
             "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE]
+    if stamps: head.append("s_mov_b64 %s, %%5" % ST_DBG)
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen.py -- do not edit"]
     for l in lines:
@@ -537,7 +626,7 @@ def render_inc(prog):
 
 
 def render_clobbers():
-    regs = ["v%d" % i for i in range(256)] + ["s%d" % i for i in range(34, 68)] + ["vcc", "scc", "memory"]
+    regs = ["v%d" % i for i in range(256)] + ["s%d" % i for i in range(34, 96)] + ["vcc", "scc", "memory"]
     return "// generated by tools/asmgen/brgen.py -- do not edit\n" + ", ".join('"%s"' % r for r in regs) + "\n"
 
 
@@ -547,6 +636,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--out":
         import os
         open(os.path.join(sys.argv[2], "tx_br_asm.inc"), "w").write(render_inc(prog))
+        open(os.path.join(sys.argv[2], "tx_br_asm_stamps.inc"), "w").write(render_inc(Gen(stamps=True).build(), stamps=True))
         open(os.path.join(sys.argv[2], "tx_br_asm_clobbers.inc"), "w").write(render_clobbers())
     elif len(sys.argv) > 1 and sys.argv[1] == "--count":
         c = prog.count()

@@ -143,6 +143,7 @@ class Emu:
         self.pend_v = np.zeros(256, bool)            # destination of an un-retired load
         self.s = np.zeros(128, np.uint32)
         self.vcc = np.zeros(64, bool)
+        self.smask = {}
         self.scc = False
         self.lds = lds_bytes                         # numpy uint8
         self.g = globals_                            # list of (base, np.uint8 array)
@@ -244,6 +245,12 @@ class Emu:
         r = self.sval(a) + self.sval(b) + int(self.scc); self.scc = r >> 32 != 0; self.s[d.i] = r & 0xFFFFFFFF
     def op_s_sub_u32(self, d, a, b):
         r = self.sval(a) - self.sval(b); self.scc = r < 0; self.s[d.i] = r & 0xFFFFFFFF
+    def op_s_subb_u32(self, d, a, b):
+        r = self.sval(a) - self.sval(b) - int(self.scc); self.scc = r < 0; self.s[d.i] = r & 0xFFFFFFFF
+    def op_s_memtime(self, d):
+        self.nclk = getattr(self, "nclk", 0) + 1000
+        def apply(v=self.nclk, i=d.i): self.s[i] = v & 0xFFFFFFFF; self.s[i + 1] = v >> 32
+        self.lgq.append(([], apply))
     def op_s_lshr_b32(self, d, a, b): self.s[d.i] = self.sval(a) >> (self.sval(b) & 31)
     def op_s_lshl_b32(self, d, a, b): self.s[d.i] = (self.sval(a) << (self.sval(b) & 31)) & 0xFFFFFFFF
     def op_s_and_b32(self, d, a, b): self.s[d.i] = self.sval(a) & self.sval(b)
@@ -278,23 +285,34 @@ class Emu:
         x = np.where(x >= (1 << (wd - 1)), x - (1 << wd), x)
         self.wr32(d, x.astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))
 
-    def op_v_add_co_u32(self, d, vcc, a, b):
+    # carry operands: "vcc" or an SGPR pair (VOP3 form); each is its own 64-lane mask
+    def _cget(self, c):
+        if isinstance(c, str): return self.vcc
+        return self.smask.get(c.i, np.zeros(64, bool))
+
+    def _cset(self, c, m):
+        if isinstance(c, str): self.vcc = m
+        else:
+            if not hasattr(self, "smask"): self.smask = {}
+            self.smask[c.i] = m
+
+    def op_v_add_co_u32(self, d, co, a, b):
         r = self.rd32(a).astype(np.uint64) + self.rd32(b).astype(np.uint64)
-        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self.vcc = (r >> np.uint64(32)) != 0
+        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self._cset(co, (r >> np.uint64(32)) != 0)
 
-    def op_v_addc_co_u32(self, d, vcc, a, b, vin):
-        r = self.rd32(a).astype(np.uint64) + self.rd32(b).astype(np.uint64) + self.vcc.astype(np.uint64)
-        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self.vcc = (r >> np.uint64(32)) != 0
+    def op_v_addc_co_u32(self, d, co, a, b, ci):
+        r = self.rd32(a).astype(np.uint64) + self.rd32(b).astype(np.uint64) + self._cget(ci).astype(np.uint64)
+        self.wr32(d, r & np.uint64(0xFFFFFFFF)); self._cset(co, (r >> np.uint64(32)) != 0)
 
-    def op_v_sub_co_u32(self, d, vcc, a, b):
+    def op_v_sub_co_u32(self, d, co, a, b):
         x, y = self.rd32(a).astype(np.int64), self.rd32(b).astype(np.int64)
         r = x - y
-        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self.vcc = r < 0
+        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self._cset(co, r < 0)
 
-    def op_v_subb_co_u32(self, d, vcc, a, b, vin):
+    def op_v_subb_co_u32(self, d, co, a, b, ci):
         x, y = self.rd32(a).astype(np.int64), self.rd32(b).astype(np.int64)
-        r = x - y - self.vcc.astype(np.int64)
-        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self.vcc = r < 0
+        r = x - y - self._cget(ci).astype(np.int64)
+        self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self._cset(co, r < 0)
 
     def op_v_mbcnt_lo_u32_b32(self, d, mask, add):
         m = int(self.rd32(mask)[0])

@@ -133,7 +133,9 @@ def main():
         emu.s[s.i] = val & 0xFFFFFFFF; emu.s[s.i + 1] = val >> 32
     emu.s[SG.NSTEP.i] = steps
     emu.s[SG.TILE.i] = TILE
-    prog = brgen.Gen().build()
+    prog = brgen.Gen(stamps=bool(os.environ.get('BR_STAMPS'))).build()
+    if os.environ.get('BR_STAMPS'):
+        dbg = np.zeros(64, np.uint8); emu.g.append((0x4000_0000, dbg)); emu.s[brgen.ST_DBG.i] = 0x4000_0000; emu.s[brgen.ST_DBG.i + 1] = 0
     t = time.time()
     emu.run(prog)
     got = out_buf.view(np.uint64).reshape(KP, N)
