@@ -20,13 +20,22 @@ sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 
-# HBM-side traffic of ONE k_blind_rotate launch over 8192 units (medium on one GPU), from the separate
-# rocprofv3 --pmc passes kept in profiles/r1_pmc_{fetch,write}_size_br_trace.csv:
-# FETCH_SIZE 1 795 972 KiB x 2 (gfx950 counts half of a 16 B/lane streaming read, MI355X_MICROARCH.md HBM)
-# + WRITE_SIZE 196 608 KiB.  The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident
-# batch of waves, mostly from the Infinity Cache.
-BR_TRAFFIC_BYTES_8192 = (1795972 * 2 + 196608) * 1024
-BR_F64_FLOP_PER_UNIT_STEP = 64 * (1080 + 336 + 2 * 648)      # per wave and CMux step: adds, muls, fmas (ISA count)
+# HBM-side traffic of ONE blind-rotation launch over 8192 units (medium on one GPU), from separate rocprofv3 --pmc
+# passes: FETCH_SIZE x 2 (gfx950 counts half of a 16 B/lane streaming read, MI355X_MICROARCH.md HBM) + WRITE_SIZE.
+# The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident batch of waves, mostly from the
+# Infinity Cache.  k_blind_rotate4 (two waves per SIMD, the kernel that runs above 4 units per CU):
+# profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
+BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate4": (1926272 * 2 + 196608) * 1024, "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
+# per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
+# compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)
+BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)
+
+
+def br_kernel_name(units, n_cus):
+    """the dispatch rule of run_br (csrc/tx_api.hip): two-wave kernel above 4 units per CU, TX_BR_VARIANT overrides"""
+    v = os.environ.get("TX_BR_VARIANT")
+    if v is not None and v != "": return "k_blind_rotate4" if int(v) == 4 else "k_blind_rotate"
+    return "k_blind_rotate4" if units > 4 * n_cus else "k_blind_rotate"
 
 
 def algorithmic_bytes_per_block(M):
@@ -178,6 +187,7 @@ def main():
         _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
         br_avg_ms = br_ms[0] / max(1, br_launches[0])
+        br_kernel = br_kernel_name(m_local * 128, torch.cuda.get_device_properties(dev_index).multi_processor_count)
         achieved = br_launch_bytes(m_local, args.n) / (br_avg_ms * 1e-3) / 1e9
         line = {
             "metric": "AES blocks transciphered/sec (medium instance)", "value": value, "unit": "AES blocks/s",
@@ -187,9 +197,9 @@ def main():
                                    f"AES_TIGHT n={args.n}, {'ECB inverse-cipher schedule of the reference' if args.mode == 'ecb' else 'CTR forward-cipher schedule'}, "
                                    f"full 10 rounds, keys resident, result LWEs left in HBM",
                        "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather"},
-            "roofline": {"bound": "hbm", "kernel": "k_blind_rotate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": br_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (BR_TRAFFIC_BYTES_8192 if (m_local * 128 == 8192 and args.n == 768) else None),
+                         "traffic": (BR_TRAFFIC_BYTES_8192[br_kernel] if (m_local * 128 == 8192 and args.n == 768) else None),
                          "avg_launch_ms": br_avg_ms, "launches": br_launches[0],
                          "algorithmic_bytes_per_launch": br_launch_bytes(m_local, args.n),
                          "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,
