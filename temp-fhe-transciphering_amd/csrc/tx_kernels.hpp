@@ -634,6 +634,7 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
     typedef Decomp<AUTO_B, AUTO_L> D;
     constexpr int NP = 2 * AUTO_L;                 // digit polynomials per step
     const int lane = w.lane;
+    TXD_STAMP_DECL();
 #pragma unroll 1
     for (int idx = 0; idx < LOGN; idx++) {
         const uint32_t t = (N >> idx) + 1;
@@ -668,6 +669,7 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
 #pragma unroll
                 for (int r = 0; r < 8; r++) Dg[q * AUTO_L + i][r] = d[i][r];
         }
+        TXD_STAMP(0);
         {   // body: g[2] += g[2](X^t)   (the key switch output starts as (0, 0, permuted body))
             uint64_t *b = gl + 2 * N;
             uint64_t own[16], pb[16];
@@ -683,12 +685,15 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
                 b[lane + 64 * m] = own[m] + ((pb[m] ^ neg) - neg);
             }
         }
+        TXD_STAMP(1);
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             cplx F[KP][8];
             zero_f(F);
             ring_pass(F, Dg, ring, TraceKeyFn{auto_f, split_stride, idx, s});
+            TXD_STAMP(2);
             fft_inv_n<KP>(F, w.tw, w.tile, lane);
+            TXD_STAMP(3);
             const int sh = s ? AUTO_SPLIT : 0;
             wave_lds_fence();
 #pragma unroll
@@ -704,8 +709,12 @@ __device__ __forceinline__ void trace_lds(uint64_t *gl, const KeyRing &ring, con
                     a[lane + 64 * (m + 8)] = cur[m + 8] + (f64_to_torus(F[c][m].y) << sh);
                 }
             }
+            TXD_STAMP(4);
         }
     }
+#ifdef TXD_STAMPS_TRACE
+    TXD_STAMP_FLUSH(LOGN);
+#endif
     wave_lds_fence();
 }
 

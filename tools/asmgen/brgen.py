@@ -70,8 +70,12 @@ ST_PREV, ST_NOW, ST_DBG = S(82, 2), S(84, 2), S(86, 2)
 
 
 class Gen:
-    def __init__(self, stamps=False):
+    def __init__(self, stamps=False, prio="I"):
         self.stamps = stamps
+        # phases that run at s_setprio 1 ("R", "F", "M", "I", "U").  The single-polynomial inverse is the phase whose
+        # exchange round trips nothing covers: a wave in it goes first when both waves of a SIMD have an instruction
+        # ready (8192 units: 47.4-47.6 against 48.4-49.4 ms; MI the same, F / RU less)
+        self.prio = prio
         self.p = Prog()
         self.buf = None
         self.vmq = []          # in-flight vector-memory ops, oldest first: sets of destination registers
@@ -148,6 +152,9 @@ class Gen:
     def ds_write(self, op, addr, src, offset=0): self.e(op, addr, src, offset=offset)
     def gload(self, op, d, voff, sbase, offset=0): self.e(op, d, voff, sbase, offset=offset)
     def gstore(self, op, voff, src, sbase, offset=0): self.e(op, voff, src, sbase, offset=offset)
+
+    def setprio(self, phase):
+        if self.prio: self.e("s_setprio", Lit(1 if phase in self.prio else 0))
 
     def stamp(self, k):
         """diagnostic build only: cycles since the previous stamp are added to accumulator k (s_memtime returns
@@ -434,6 +441,7 @@ class Gen:
         e = self.e
         self.p.label("L_step%=")
         # ---- rotation amount of this step (wave-uniform), prefetch of the next mask element
+        self.setprio("R")
         self.c("---- modswitch(ct[i]) -> rot; base = (lane - rot) mod 2N")
         # loop head: the only vector-memory operation that can be in flight is the load of this step's mask element
         # (from the prologue on entry; on the back edge it retired behind the key loads).  A full wait makes both
@@ -523,11 +531,13 @@ class Gen:
             key_ptrs(col)
             for k in range(EARLY): issue(col, k)
         polys = [[quad(D[p], r) for r in range(8)] for p in range(3)]
+        self.setprio("F")
         polys, spare = self.fwd3(polys, xq, before_pass3=lambda: early(0))
         self.stamp(1)
         # ---- per column: multiply-accumulate against the key, inverse transform, update
         for col in range(3):
             self.c("---- column %d: F = sum_q D_q * key[q][col]" % col)
+            self.setprio("M")
             ring = ring_of(col)
             for k in range(EARLY, NG): issue(col, k)
             Fq = [quad(F, r) for r in range(8)]
@@ -546,8 +556,10 @@ class Gen:
                 for kk in (k, k + 1):
                     if kk + NG < len(stream): issue(col, kk + NG)
             self.stamp(2)
+            self.setprio("I")
             v, sp2 = self.inv1(Fq, [quad(X, r) for r in range(12)])
             self.stamp(3)
+            self.setprio("U")
             if col < 2: early(col + 1)              # lands during the conversions below (they use X[0..3] only)
             self.c("---- column %d: accumulator += round(inverse)" % col)
             tmp = [(V(X + 4 * k, 2), V(X + 4 * k + 2, 2)) for k in range(4)]     # X[0..3]: free again after the inverse
@@ -631,7 +643,8 @@ def render_clobbers():
 
 
 if __name__ == "__main__":
-    g = Gen()
+    import os as _os
+    g = Gen(prio=_os.environ.get("BR_PRIO", "I"))
     prog = g.build()
     if len(sys.argv) > 2 and sys.argv[1] == "--out":
         import os

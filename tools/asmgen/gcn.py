@@ -257,6 +257,7 @@ class Emu:
     def op_s_cmp_lt_u32(self, a, b): self.scc = self.sval(a) < self.sval(b)
     def op_s_cbranch_scc1(self, lab): return lab if self.scc else None
     def op_s_nop(self, n): pass
+    def op_s_setprio(self, n): pass
 
     def op_s_waitcnt(self, vm=None, lgkm=None):
         if vm is not None: self.retire(self.vmq, vm)
