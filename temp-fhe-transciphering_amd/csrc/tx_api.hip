@@ -37,6 +37,7 @@ struct tx_ctx {
     size_t auto_split_stride = 0;
     cplx *tw = nullptr, *tw256 = nullptr;
     int num_cus = 0;
+    int trace_variant = 4;                  // k_extract_trace4 (generated trace loop); TX_TRACE_VARIANT=0: the hipcc kernel
     int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4 forces a kernel
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
@@ -132,6 +133,11 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     }
     c->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("TX_BR_VARIANT")) c->br_variant = atoi(e);
+    if (const char *e = getenv("TX_TRACE_VARIANT")) c->trace_variant = atoi(e);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TR4) != hipSuccess) {
+        fail("tx_create: cannot reserve LDS for the generated trace kernel"); delete c; return nullptr;
+    }
     return c;
 }
 
@@ -346,6 +352,10 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {
     ev_begin(c, F_TRACE);
+    if (c->trace_variant == 4)
+        hipLaunchKernelGGL(k_extract_trace4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, acc, glev,
+                           (int)count, c->auto_f, c->auto_split_stride, c->tw);
+    else
     hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TRACE, c->stream, acc, glev,
                        (int)count, c->auto_f, c->auto_split_stride, c->tw);
     ev_end(c);

@@ -358,4 +358,78 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// k_extract_trace4: k_extract_trace with trace_lds() replaced by the generated loop of tools/asmgen/trgen.py
+// (tx_trace_asm.inc): one wave per SIMD as before, but the six digit transforms of a step are parked in accumulation
+// registers, which leaves room for two key register sets (the LDS read of the next key polynomial is in flight
+// while the current one is multiplied) and three-way interleaved transforms in both directions.  LDS image: the
+// compact twiddles of k_blind_rotate3/4, then per wave an unpadded 8 KiB tile (= that wave's ring slot) and the
+// 24 KiB GLWE.  Same ring protocol (KeyRing, tx_kernels.hpp): every wave takes part in every barrier, so idle
+// waves of the last workgroup shadow the last unit.  Bit-identical to k_extract_trace and the oracle.
+// ------------------------------------------------------------------------------------------
+constexpr size_t TR4_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)GL * sizeof(uint64_t);
+constexpr size_t LDS_BYTES_TR4 = BR3_TW_CPLX * sizeof(cplx) + WAVES * TR4_WAVE_BYTES;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int unit = blockIdx.x * WAVES + wave;
+    const bool active = unit < count * CBS_L;       // idle waves of the last workgroup redo the last unit (in their
+    if (!active) unit = count * CBS_L - 1;          // own LDS): every wave takes part in the key ring's barriers
+    unsigned char *slot0 = lds + BR3_TW_CPLX * sizeof(cplx);
+    unsigned char *tile = slot0 + (size_t)wave * TR4_WAVE_BYTES;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + H * sizeof(cplx));
+    const int ctx = unit / CBS_L, lvl = unit % CBS_L;
+    const uint64_t *a = acc + (size_t)ctx * GL;
+    // buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const  (as k_extract_trace)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int j = lane + 64 * m, s = j + lvl;
+            uint64_t x = (s < N) ? a[q * N + s] : (uint64_t)0 - a[q * N + s - N];
+            gl[q * N + j] = (j == 0) ? (x >> LOGN) : (uint64_t)0 - (((uint64_t)0 - x) >> LOGN);
+        }
+    {
+        const uint64_t b0 = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
+#pragma unroll
+        for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
+    }
+    const uint32_t slot0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)slot0);
+    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
+    const uint32_t split_bytes = (uint32_t)(split_stride * sizeof(cplx));
+#ifdef TXD_STAMPS_TRACE
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps + 8;
+    if ((threadIdx.x & 63) == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)LOGN;
+    asm volatile(
+#include "tx_trace_asm_stamps.inc"
+        :
+        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(dbg)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#else
+    asm volatile(
+#include "tx_trace_asm.inc"
+        :
+        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#endif
+    if (!active) return;
+    uint64_t *o = glev + (size_t)unit * GL;
+    const int lane2 = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) o[q * N + lane2 + 64 * m] = gl[q * N + lane2 + 64 * m];
+}
+
 }  // namespace txd

@@ -22,20 +22,30 @@ def test_stamped_variant_is_the_same_arithmetic(oracle):
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_generated_trace_loop_equals_oracle_four_waves(oracle):
+    """a whole workgroup: four emulated waves share the LDS image, fill the key ring by LDS-DMA quarters and meet at
+    every s_barrier; result against txo_trace() with real automorphism keys"""
+    r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu_trace.py"), "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
 def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
-    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_clobbers.inc"):
+    subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])
+    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_clobbers.inc", "tx_trace_asm.inc", "tx_trace_asm_stamps.inc",
+              "tx_trace_asm_clobbers.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 
 def test_register_budget_and_no_scratch():
     """the loop must fit 256 VGPRs with nothing in scratch: two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, gcn
-    prog = brgen.Gen().build()
-    top = 0
-    for i in prog.ins:
-        for x in i.a:
-            if isinstance(x, gcn.V): top = max(top, x.i + x.n)
-    assert top <= 256
-    assert not any(i.op.startswith("scratch_") for i in prog.ins)
+    import brgen, trgen, gcn
+    for prog in (brgen.Gen().build(), trgen.TraceGen().build()):
+        top = 0
+        for i in prog.ins:
+            for x in i.a:
+                if isinstance(x, gcn.V): top = max(top, x.i + x.n)
+                if isinstance(x, gcn.S) and x.i != 124: assert x.i + x.n <= 96, "the top six SGPRs are VCC / flat scratch / xnack"
+        assert top <= 256
+        assert not any(i.op.startswith("scratch_") for i in prog.ins)

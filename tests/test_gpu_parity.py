@@ -408,3 +408,20 @@ def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):
     assert np.array_equal(auto, one_wave)
     pick = np.r_[0:6, cnt - 6:cnt]
     assert np.array_equal(auto[pick], r.octx.blind_rotate(lwe[pick]))
+
+
+def test_trace_kernels_agree(rig256, monkeypatch):
+    """k_extract_trace4 (generated loop, the default) and k_extract_trace (hipcc) on a ragged launch: same bits, and
+    the oracle's on a sample"""
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(29)
+    acc = rng.integers(0, 1 << 63, (9, 3, 1024), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (9, 3, 1024), dtype=np.uint64)
+    new = r.eng.extract_trace(acc)                      # 63 units: the last workgroup has one idle wave
+    monkeypatch.setenv("TX_TRACE_VARIANT", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    old = e0.extract_trace(acc)
+    e0.close()
+    assert np.array_equal(new, old)
+    assert np.array_equal(new[:2], r.octx.extract_trace(acc[:2]))

@@ -101,6 +101,7 @@ class Gen:
         if op.startswith("ds_read"): self.lgq.append(self.regs(a[0]))
         elif op.startswith("ds_write"): self.lgq.append(set())
         elif op == "s_memtime": self.lgq.append(set())
+        elif op.startswith("global_load_lds"): pass          # LDS-DMA: no destination register; the caller tags it
         elif op.startswith("global_load"): self.vmq.append(self.regs(a[0]))
         elif op.startswith("global_store"): self.vmq.append(set())
 
@@ -305,6 +306,7 @@ class Gen:
         """polys: three lists of 8 quads (digits as doubles); xq: 12 free quads of region X.
         On return polys[p][r] is the quad holding F-layout register r of polynomial p."""
         tw, spare = xq[:8], xq[8]
+        home_lo = [min(q.i for q in polys[p]) for p in range(3)]
         self.c("forward x3: twist")
         self.load_tw(tw, 0, 8)
         for p in range(3):
@@ -334,7 +336,7 @@ class Gen:
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
             polys[p], spare = self.dft8(polys[p], spare, +1)
-            polys[p], spare = self.home(polys[p], spare, D[p], D[p] + 32)
+            polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
         return polys, spare
 
     def inv1(self, v, xq):
@@ -360,10 +362,43 @@ class Gen:
         self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist)")
         self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
         self.load_tw(tw, 0, 8)
+        home_lo = min(q.i for q in v)
         v, spare = self.dft8(v, spare, -1)
-        v, spare = self.home(v, spare, F, F + 32)
+        v, spare = self.home(v, spare, home_lo, home_lo + 32)
         self.cmul_all([(v[m], tw[m]) for m in range(8)], spare, conj=True)
         return v, spare
+
+    def inv3(self, polys, xq):
+        """unnormalised inverses of three polynomials together (fft_inv_n<3>): polynomial p's tile round trip is
+        in flight while the others' butterflies issue.  polys: three lists of 8 quads; xq: >= 9 free quads."""
+        tw, spare = xq[:8], xq[8]
+        home_lo = [min(q.i for q in polys[p]) for p in range(3)]
+        self.c("inverse x3: pass 3' (dft8, exchange lo)")
+        self.load_tw(tw, 0, 7, compact=True)
+        for p in range(3):
+            polys[p], spare = self.dft8(polys[p], spare, -1)
+            self.xchg_lo_write(polys[p])
+            free = sorted(polys[p] + [spare], key=lambda q: q.i)
+            polys[p], spare = free[:8], free[8]
+            self.xchg_read(polys[p], swz=True)
+        self.c("inverse x3: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
+        for p in range(3):
+            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
+            if p == 2: self.load_tw(tw, 8, 7)                # the pass-A rows replace the pass-B rows after their last use
+            polys[p], spare = self.dft8(polys[p], spare, -1)
+            self.xchg_hi_write(polys[p])
+            free = sorted(polys[p] + [spare], key=lambda q: q.i)
+            polys[p], spare = free[:8], free[8]
+            self.xchg_read(polys[p], swz=False)
+        self.c("inverse x3: pass 1' (pass-A twiddles conj, dft8, untwist)")
+        for p in range(3):
+            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
+            if p == 2: self.load_tw(tw, 0, 8)
+            polys[p], spare = self.dft8(polys[p], spare, -1)
+            polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
+        for p in range(3):
+            self.cmul_all([(polys[p][m], tw[m]) for m in range(8)], spare, conj=True)
+        return polys, spare
 
     # ---------------------------------------------------------------- integer <-> double
     def digit_pair(self, q, own_lo, own_hi, sgn, t, cy=VCC):

@@ -51,8 +51,23 @@ class S:
     def hi(self): return S(self.i + 1)
 
     def __str__(self):
+        if self.i == 124 and self.n == 1: return "m0"
         s = "s%d" % self.i if self.n == 1 else "s[%d:%d]" % (self.i, self.i + self.n - 1)
         return "-" + s if self.neg else s
+
+
+class A:
+    """accumulation register (AGPR): reachable by VALU only through v_accvgpr_read/write"""
+    __slots__ = ("i", "n")
+
+    def __init__(self, i, n=1):
+        assert 0 <= i and i + n <= 256
+        self.i, self.n = i, n
+
+    def __str__(self): return "a%d" % self.i if self.n == 1 else "a[%d:%d]" % (self.i, self.i + self.n - 1)
+
+
+M0 = S(124)
 
 
 class Lit:
@@ -140,6 +155,7 @@ class Emu:
 
     def __init__(self, lds_bytes, globals_):
         self.v = np.zeros((256, 64), np.uint32)
+        self.acc = np.zeros((256, 64), np.uint32)    # AGPRs
         self.pend_v = np.zeros(256, bool)            # destination of an un-retired load
         self.s = np.zeros(128, np.uint32)
         self.vcc = np.zeros(64, bool)
@@ -210,7 +226,8 @@ class Emu:
             for r in regs: self.pend_v[r] = False
 
     # ---- execution
-    def run(self, prog, max_ins=10_000_000):
+    def run_gen(self, prog, max_ins=50_000_000):
+        """executes until the end; yields at every s_barrier (the caller decides when the wave may go on)"""
         ins = prog.ins
         labels = {i.a[0]: k for k, i in enumerate(ins) if i.op == "label"}
         pc = 0
@@ -221,10 +238,16 @@ class Emu:
             self.nexec += 1
             self.stats[i.op] = self.stats.get(i.op, 0) + 1
             if self.nexec > max_ins: raise RuntimeError("instruction budget exceeded")
+            if i.op == "s_barrier":
+                yield "barrier"
+                continue
             j = self.step(i)
             if j is not None: pc = labels[j]
         # program end: everything must have been waited for
         if self.vmq or self.lgq: raise Poison("program ended with memory operations in flight")
+
+    def run(self, prog, max_ins=50_000_000):
+        for _ in self.run_gen(prog, max_ins): pass          # a wave alone: barriers are trivially passed
 
     def step(self, i):
         op, a, kw = i.op, i.a, i.kw
@@ -256,6 +279,7 @@ class Emu:
     def op_s_and_b32(self, d, a, b): self.s[d.i] = self.sval(a) & self.sval(b)
     def op_s_cmp_lt_u32(self, a, b): self.scc = self.sval(a) < self.sval(b)
     def op_s_cbranch_scc1(self, lab): return lab if self.scc else None
+    def op_s_mul_i32(self, d, a, b): self.s[d.i] = (self.sval(a) * self.sval(b)) & 0xFFFFFFFF
     def op_s_nop(self, n): pass
     def op_s_setprio(self, n): pass
 
@@ -275,6 +299,14 @@ class Emu:
     def op_v_lshrrev_b32(self, d, a, b): self.wr32(d, self.rd32(b) >> (self.rd32(a) & 31))
     def op_v_lshl_add_u32(self, d, a, b, c): self.wr32(d, (self.rd32(a) << (self.rd32(b) & 31)) + self.rd32(c))
     def op_v_add3_u32(self, d, a, b, c): self.wr32(d, self.rd32(a) + self.rd32(b) + self.rd32(c))
+
+    def op_v_alignbit_b32(self, d, hi, lo, sh):
+        x = (self.rd32(hi).astype(np.uint64) << np.uint64(32)) | self.rd32(lo).astype(np.uint64)
+        self.wr32(d, (x >> (self.rd32(sh).astype(np.uint64) & np.uint64(31))) & np.uint64(0xFFFFFFFF))
+    def op_v_mul_lo_u32(self, d, a, b):
+        self.wr32(d, (self.rd32(a).astype(np.uint64) * self.rd32(b).astype(np.uint64)) & np.uint64(0xFFFFFFFF))
+    def op_v_accvgpr_write_b32(self, d, a): self.acc[d.i] = self.rd32(a)
+    def op_v_accvgpr_read_b32(self, d, a): self.wr32(d, self.acc[a.i].copy())
 
     def op_v_bfe_u32(self, d, a, off, w):
         o, wd = int(self.rd32(off)[0]) & 31, int(self.rd32(w)[0]) & 31
@@ -341,7 +373,7 @@ class Emu:
 
     def _ds_read(self, d, a, offset, nd):
         addr = self._lds_addr(a, offset)
-        assert (addr % (4 * min(nd, 2)) == 0).all() or nd == 4, "misaligned LDS read"
+        assert (addr % (4 * min(nd, 2)) == 0).all(), "misaligned LDS read"
         if nd == 4: assert (addr % 16 == 0).all(), "ds_read_b128 must be 16-byte aligned"
         assert addr.min() >= 0 and addr.max() + 4 * nd <= self.lds.size, "LDS read out of range: %d..%d" % (addr.min(), addr.max())
         regs = list(range(d.i, d.i + nd))
@@ -354,6 +386,7 @@ class Emu:
             for k in range(nd): self.v[base + k] = w[(addr >> 2) + k]
         self.lgq.append((regs, apply))
 
+    def op_ds_read_b32(self, d, a, offset=0): self._ds_read(d, a, offset, 1)
     def op_ds_read_b64(self, d, a, offset=0): self._ds_read(d, a, offset, 2)
     def op_ds_read_b128(self, d, a, offset=0): self._ds_read(d, a, offset, 4)
 
@@ -369,6 +402,12 @@ class Emu:
             for k, x in enumerate(vals): w[(addr >> 2) + k] = x
         self.lgq.append(([], apply))
 
+    def op_ds_write_b32(self, a, src, offset=0):
+        addr = self._lds_addr(a, offset)
+        assert (addr % 4 == 0).all() and addr.min() >= 0 and addr.max() + 4 <= self.lds.size
+        val = self.rd32(src)
+        def apply(addr=addr, val=val): self.lds.view(np.uint32)[addr >> 2] = val
+        self.lgq.append(([], apply))
     def op_ds_write_b64(self, a, src, offset=0): self._ds_write(a, src, offset, 2)
     def op_ds_write_b128(self, a, src, offset=0): self._ds_write(a, src, offset, 4)
 
@@ -391,6 +430,19 @@ class Emu:
                 self.v[base:base + nd, l] = arr[o:o + 4 * nd].view(np.uint32)
         self.vmq.append((regs, apply))
 
+    def op_global_load_lds_dwordx4(self, voff, sbase, offset=0):
+        """LDS-DMA: lane l's 16 bytes go to LDS[M0 + 16 l]; counted by vmcnt; no destination registers"""
+        assert offset == 0, "keep LDS-DMA loads free of an instruction offset (it applies to the LDS address too)"
+        addr = self._gaddr(voff, sbase, offset)
+        m0 = int(self.s[124])
+        assert m0 % 16 == 0 and 0 <= m0 and m0 + 1024 <= self.lds.size, "LDS-DMA destination out of range: %d" % m0
+
+        def apply(addr=addr, m0=m0):
+            for l in range(64):
+                arr, o = self.gmem(int(addr[l]), 16)
+                self.lds[m0 + 16 * l: m0 + 16 * l + 16] = arr[o:o + 16]
+        self.vmq.append(([], apply))
+
     def op_global_load_dwordx4(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 4)
     def op_global_load_dwordx2(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 2)
 
@@ -404,3 +456,19 @@ class Emu:
                 arr, o = self.gmem(int(addr[l]), 8)
                 arr[o:o + 8].view(np.uint32)[:] = [vals[0][l], vals[1][l]]
         self.vmq.append(([], apply))
+
+
+def run_group(emus, prog):
+    """several waves of one workgroup (they share `lds`): each runs to its next s_barrier, then all go on"""
+    gens = [e.run_gen(prog) for e in emus]
+    alive = [True] * len(gens)
+    while any(alive):
+        states = []
+        for k, g in enumerate(gens):
+            if not alive[k]: continue
+            try:
+                states.append(next(g))
+            except StopIteration:
+                alive[k] = False
+                states.append("end")
+        if len(set(states)) != 1: raise RuntimeError("waves disagree at a barrier: %s" % states)
