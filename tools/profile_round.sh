@@ -10,7 +10,7 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 > $out/bench_profiled.log 2>&1
-tail -1 $out/bench_profiled.log > $out/bench_line_profiled.json
+grep "^{" $out/bench_profiled.log | tail -1 > $out/bench_line_profiled.json
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o fetch --output-format csv -- python3 $R/tools/br_only.py 768 8192 1 > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o write --output-format csv -- python3 $R/tools/br_only.py 768 8192 1 > $out/write.log 2>&1
 python3 - <<PY
