@@ -1,8 +1,8 @@
 """exploratory: compare a GPU dump of tools/debug_trace.py (gpurun_out/dbg_trace) with the emulator run of the same
 inputs for TR_STEPS steps"""
 import ctypes as C, os, sys, numpy as np
-HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen")); sys.path.insert(0, HERE)
 import gcn, trgen, oracle_lib as O
 N, H, KP = 1024, 512, 3
 TW_BYTES = (15 * 64 + 7 * 8) * 16; WAVE_LDS = 32768

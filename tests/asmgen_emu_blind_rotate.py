@@ -3,7 +3,7 @@ oracle's primitives (txo_fft_forward_int, txo_fft_inverse_add, txo_decompose_idx
 CMux steps with a realistic random Fourier key.  Everything must match bit for bit, and no register may be
 read before its load was waited for (gcn.Poison).
 
-    python3 tools/asmgen/test_emu.py [steps=2] [seed=1]
+    python3 tests/asmgen_emu_blind_rotate.py [steps=2] [seed=1]
 """
 import ctypes as C
 import os
@@ -12,8 +12,8 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, HERE)
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen"))
 import gcn
 import brgen
 

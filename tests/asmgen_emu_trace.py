@@ -2,7 +2,7 @@
 key ring filled by their LDS-DMA quarters, every s_barrier honoured -- against the CPU oracle's txo_trace() on the
 same four GLWEs with real automorphism keys (oracle keygen at n = 256).  Must match bit for bit.
 
-    python3 tools/asmgen/test_emu_trace.py [seed=1]
+    python3 tests/asmgen_emu_trace.py [seed=1]
 """
 import ctypes as C
 import os
@@ -11,9 +11,9 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen"))
 sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gcn
 import trgen
 import oracle_lib as O

@@ -12,20 +12,20 @@ CSRC = os.path.join(ROOT, "temp-fhe-transciphering_amd", "csrc")
 
 def test_generated_loop_equals_oracle_in_the_emulator(oracle):
     for steps, seed in ((3, 1), (2, 77)):
-        r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu.py"), str(steps), str(seed)], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), str(steps), str(seed)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
 def test_stamped_variant_is_the_same_arithmetic(oracle):
     env = dict(os.environ, BR_STAMPS="1")
-    r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
 def test_generated_trace_loop_equals_oracle_four_waves(oracle):
     """a whole workgroup: four emulated waves share the LDS image, fill the key ring by LDS-DMA quarters and meet at
     every s_barrier; result against txo_trace() with real automorphism keys"""
-    r = subprocess.run([sys.executable, os.path.join(GEN, "test_emu_trace.py"), "5"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_trace.py"), "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 

@@ -4,7 +4,7 @@ hipcc cannot hold this kernel's working set in 256 registers (it spills 50-100 r
 scratch traffic shares the vector-memory counter with the key stream), so the loop is emitted with a fixed
 register map, explicit software pipelining and counted waits.  The arithmetic is, operation for operation, the
 one of k_blind_rotate / the CPU oracle (oracle/txo_fft.c, txo_core.c): same butterfly network, same fma
-placement, same summation order -- outputs are bit-identical.  tools/asmgen/test_emu.py runs the emitted
+placement, same summation order -- outputs are bit-identical.  tests/asmgen_emu_blind_rotate.py runs the emitted
 stream in a lane-exact emulator (gcn.py) against the oracle's primitives; tests/test_gpu_parity.py compares the
 kernel with the oracle on the GPU.
 
