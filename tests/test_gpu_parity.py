@@ -425,3 +425,28 @@ def test_trace_kernels_agree(rig256, monkeypatch):
     e0.close()
     assert np.array_equal(new, old)
     assert np.array_equal(new[:2], r.octx.extract_trace(acc[:2]))
+
+
+def test_large_instance_properties(rig768):
+    """size 3 as this repo defines it (4096 values = 512 blocks, CTR): larger than one workspace chunk (128 blocks), so
+    the batch is split; properties that need no oracle: exact decryption, block independence across a chunk boundary,
+    the homomorphic max over the first chunk's values"""
+    import txclient
+    r = rig768
+    rng = np.random.RandomState(11)
+    db = rng.randint(0, 65536, size=512 * 8).astype(np.uint16)
+    pt = pack_u16(db)
+    ct = txclient.aes_ctr_crypt(AES_KEY, AES_IV, pt)
+    out = r.eng.transcipher(ct, iv=AES_IV)
+    bits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, out)
+    vals = (bits.reshape(-1, 16) * (1 << np.arange(15, -1, -1))).sum(axis=1)
+    assert np.array_equal(vals.astype(np.uint16), db)
+    # blocks 127 and 128 sit on either side of the chunk boundary: alone (with their counters) they give the same ciphertexts
+    ctr = int.from_bytes(AES_IV, "big")
+    for b in (127, 128):
+        iv_b = ((ctr + b) % (1 << 128)).to_bytes(16, "big")
+        alone = r.eng.transcipher(ct[16 * b:16 * b + 16], iv=iv_b)
+        assert np.array_equal(alone, out[128 * b:128 * b + 128])
+    mx = r.eng.max_u16(out[:16 * 64])
+    mbits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, mx)
+    assert int("".join(str(int(b)) for b in mbits), 2) == int(db[:64].max())
