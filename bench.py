@@ -25,7 +25,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident batch of waves, mostly from the
 # Infinity Cache.  k_blind_rotate4 (two waves per SIMD, the kernel that runs above 4 units per CU):
 # profiles/r2_final_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
-BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate4": (1779967 * 2 + 196608) * 1024, "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
+BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": None, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024, "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
 # per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
 # compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)
@@ -34,8 +34,8 @@ BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)
 def br_kernel_name(units, n_cus):
     """the dispatch rule of run_br (csrc/tx_api.hip): two-wave kernel above 4 units per CU, TX_BR_VARIANT overrides"""
     v = os.environ.get("TX_BR_VARIANT")
-    if v is not None and v != "": return "k_blind_rotate4" if int(v) == 4 else "k_blind_rotate"
-    return "k_blind_rotate4" if units > 4 * n_cus else "k_blind_rotate"
+    if v is not None and v != "": return {5: "k_blind_rotate5", 4: "k_blind_rotate4"}.get(int(v), "k_blind_rotate")
+    return "k_blind_rotate5" if units > 4 * n_cus else "k_blind_rotate"
 
 
 def algorithmic_bytes_per_block(M):

@@ -127,6 +127,8 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess ||
 #endif
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate5), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR5) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); delete c; return nullptr;
@@ -215,6 +217,13 @@ extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
 }
 
 #ifdef TXD_STAMPS
+extern "C" int tx_debug_wave_times(tx_ctx *c, unsigned long long *out, int n)
+{
+    if (!c || !out || n > 2 * 4096) return fail("tx_debug_wave_times: bad argument");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(txd::txd_wave_rt), (size_t)n * sizeof(unsigned long long)));
+    return 0;
+}
 // diagnostic builds only: per-phase cycle sums of one wave of the last k_blind_rotate launch (tools/br_only.py)
 extern "C" int tx_debug_stamps(tx_ctx *c, unsigned long long *out16)
 {
@@ -331,12 +340,17 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
-    // Two kernels, same results bit for bit.  k_blind_rotate4 (generated assembly, two waves per SIMD, two 256-thread
-    // workgroups per CU) wins once every SIMD can hold two units: more than 4 units per CU.  Below that a launch is one
-    // wave per SIMD anyway and k_blind_rotate (three transforms interleaved in 512 registers) is the faster one
-    // (1024 units: 8.0 against 8.5 ms; 8192 units: 59.7 against 47.6 ms).
-    const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 4 : 0);
-    if (variant == 4) {
+    // Three kernels, same results bit for bit.  Above 4 units per CU every SIMD can hold two units: k_blind_rotate5 (generated
+    // assembly, two waves per SIMD in one persistent 512-thread workgroup per CU, fair arbitration between the two waves of a
+    // SIMD) runs; k_blind_rotate4 (the same loop in two independent 256-thread workgroups per CU) is 1 % behind it
+    // (TX_BR_VARIANT=4).  Below that a launch is one wave per SIMD anyway and k_blind_rotate (three transforms interleaved in
+    // 512 registers) is the faster one (1024 units: 8.0 against 8.5 ms; 8192 units: 59.7 against 46.6 ms).
+    const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 5 : 0);
+    if (variant == 5) {
+        const size_t wgs = std::min<size_t>((count + BR5_WAVES - 1) / BR5_WAVES, (size_t)c->num_cus);     // persistent, one per CU
+        hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc,
+                           (int)count, (int)c->p.n, c->bsk_f, c->tw);
+    } else if (variant == 4) {
         hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
                            (int)c->p.n, c->bsk_f, c->tw);
 #ifdef TXD_WITH_BR3

@@ -337,8 +337,12 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     }
     const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
     uint64_t *out = acc_out + (size_t)unit * GL;
+#ifdef TXD_STAMPS   // per workgroup (its wave 0): s_memrealtime at the start and the end of the unit
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const int rt_slot = (wave == 0 && blockIdx.x < 4096) ? (int)blockIdx.x : -1;
+#endif
 #ifdef TXD_STAMPS   // diagnostic build: per-phase cycle sums of one wave (tools/br_only.py); every other wave writes to a sink
-    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps + 8;
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
     if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
     asm volatile(
 #include "tx_br_asm_stamps.inc"
@@ -347,6 +351,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
         :
 #include "tx_br_asm_clobbers.inc"
     );
+    if (rt_slot >= 0 && (threadIdx.x & 63) == 0) { txd_wave_rt[2 * rt_slot] = rt0; txd_wave_rt[2 * rt_slot + 1] = __builtin_amdgcn_s_memrealtime(); }
 #else
     asm volatile(
 #include "tx_br_asm.inc"
@@ -355,6 +360,89 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
         :
 #include "tx_br_asm_clobbers.inc"
     );
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blind_rotate5: the generated loop with FAIR arbitration.  With two independent workgroups per CU the older wave of
+// every SIMD wins each arbitration (25 k against 40 k cycles per step): the workgroups of a CU finish far apart and the
+// last one runs unpaired -- about 4.5 ms of every launch, whatever its size.  Here the two waves of a SIMD belong to ONE
+// 512-thread workgroup (waves w and w + 4: a workgroup's waves go to the four SIMDs cyclically), publish their step
+// counters in LDS every step, and the one that is behind runs at a higher priority (s_setprio 2/3 against 0/1): both
+// advance at the same rate and the eight units of a workgroup finish together.  LDS: twiddles + 8 x 16 KiB + counters.
+// ------------------------------------------------------------------------------------------
+constexpr int BR5_WAVES = 8;
+constexpr size_t LDS_BYTES_BR5 = BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WAVE_BYTES + BR5_WAVES * sizeof(uint32_t);
+
+// Persistent: `gridDim.x` workgroups (one per CU), wave w of workgroup b takes units b * 8 + w + k * 8 * gridDim.x,
+// k = 0, 1, ... -- a static share, so that no wave picks up an extra 11 ms unit at the end; the step counters keep
+// counting across units.  A wave leaves when its share is done (it then reads as "finished" to its partner).
+__global__ __launch_bounds__(512, 2)
+void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    uint32_t *prog = reinterpret_cast<uint32_t *>(lds + BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WAVE_BYTES);
+    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int first = blockIdx.x * BR5_WAVES + wave, stride = (int)gridDim.x * BR5_WAVES;
+    // a wave without a unit is "finished" from the start: its partner is never behind it
+    if ((threadIdx.x & 63) == 0) prog[wave] = (first < count) ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    unsigned char *tile = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES;
+    uint64_t *bl = reinterpret_cast<uint64_t *>(tile) + N;
+    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
+    const uint32_t prog_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)prog);
+    const uint32_t prog_a = prog_addr + 4u * (uint32_t)wave, prog_b = prog_addr + 4u * (uint32_t)(wave ^ 4);
+    uint32_t done_steps = 0;
+#ifdef BR5_STAGGER      // experiment: the second wave of every SIMD starts half a step late (waves of one program can lock in phase)
+    if (wave >= 4) for (int k = 0; k < BR5_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
+#endif
+#ifdef TXD_STAMPS
+    if ((threadIdx.x & 63) == 0 && first < 4096) txd_wave_rt[2 * first] = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll 1
+    for (int unit = first; unit < count; unit += stride) {
+        const int lane = threadIdx.x & 63;
+        const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+        {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+            const int rot = 2 * N - (int)modswitch(ct[n]);
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                int src = lane + 64 * m - rot;
+                uint64_t neg = 0;
+                if (src < 0) { src += N; neg = ~neg; }
+                if (src < 0) { src += N; neg = ~neg; }
+                uint64_t x = test_vector(src);
+                bl[lane + 64 * m] = (x ^ neg) - neg;
+            }
+        }
+        uint64_t *out = acc_out + (size_t)unit * GL;
+#ifdef TXD_STAMPS
+        unsigned long long *dbg = (unit == TXD_STAMP_BLOCK * 4 + TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
+        if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
+        asm volatile(
+#include "tx_br_asm_fair_stamps.inc"
+            :
+            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps), "s"(dbg)
+            :
+#include "tx_br_asm_clobbers.inc"
+        );
+#else
+        asm volatile(
+#include "tx_br_asm_fair.inc"
+            :
+            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps)
+            :
+#include "tx_br_asm_clobbers.inc"
+        );
+#endif
+        done_steps += (uint32_t)n;
+    }
+    if ((threadIdx.x & 63) == 0) prog[wave] = 0xFFFFFFFFu;      // finished: the partner is never "behind" this wave again
+#ifdef TXD_STAMPS
+    if ((threadIdx.x & 63) == 0 && first < 4096) txd_wave_rt[2 * first + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -405,7 +493,7 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
     const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
     const uint32_t split_bytes = (uint32_t)(split_stride * sizeof(cplx));
 #ifdef TXD_STAMPS_TRACE
-    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps + 8;
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
     if ((threadIdx.x & 63) == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)LOGN;
     asm volatile(
 #include "tx_trace_asm_stamps.inc"

@@ -22,6 +22,8 @@ constexpr int LOGN = 10;
 
 #ifdef TXD_STAMPS       // diagnostic build: s_memtime per phase of k_blind_rotate, summed over the steps of one wave
 __device__ unsigned long long txd_stamps[16];                   // read back by tx_debug_stamps(); no output depends on it
+__device__ unsigned long long txd_stamps_sink[16];
+__device__ unsigned long long txd_wave_rt[2 * 4096];           // per wave slot: s_memrealtime at the start / the end of its share (k_blind_rotate5)              // where every other wave of a generated loop writes its stamps
 #define TXD_STAMP_DECL() unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(); FftStamp fst = {{0, 0, 0, 0}, 0}
 #define TXD_FST (&fst)
 #define TXD_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long st_n = __builtin_amdgcn_s_memtime(); \

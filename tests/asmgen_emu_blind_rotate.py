@@ -20,7 +20,7 @@ import brgen
 N, H, KP = 1024, 512, 3
 TW_BYTES = (15 * 64 + 7 * 8) * 16
 TILE = TW_BYTES                      # wave 0's tile
-LDS_BYTES = TW_BYTES + 16384
+LDS_BYTES = TW_BYTES + 16384 + 64      # + the two step counters of the fair variant
 
 
 def oracle():
@@ -133,9 +133,13 @@ def main():
         emu.s[s.i] = val & 0xFFFFFFFF; emu.s[s.i + 1] = val >> 32
     emu.s[SG.NSTEP.i] = steps
     emu.s[SG.TILE.i] = TILE
-    prog = brgen.Gen(stamps=bool(os.environ.get('BR_STAMPS'))).build()
+    fair = os.environ.get('BR_FAIR')            # '0': partner never ahead, '1': partner always ahead (both priority paths)
+    prog = brgen.Gen(stamps=bool(os.environ.get('BR_STAMPS')), fair=fair is not None).build()
+    if fair is not None:
+        emu.s[SG.PROGA.i] = TW_BYTES + 16384; emu.s[SG.PROGB.i] = TW_BYTES + 16384 + 4; emu.s[SG.PBASE.i] = 1536
+        lds[TW_BYTES + 16384 + 4: TW_BYTES + 16384 + 8].view(np.uint32)[0] = 0xFFFFFFFF if fair == '1' else 0
     if os.environ.get('BR_STAMPS'):
-        dbg = np.zeros(64, np.uint8); emu.g.append((0x4000_0000, dbg)); emu.s[brgen.ST_DBG.i] = 0x4000_0000; emu.s[brgen.ST_DBG.i + 1] = 0
+        dbg = np.zeros(128, np.uint8); emu.g.append((0x4000_0000, dbg)); emu.s[brgen.ST_DBG.i] = 0x4000_0000; emu.s[brgen.ST_DBG.i + 1] = 0
     t = time.time()
     emu.run(prog)
     got = out_buf.view(np.uint64).reshape(KP, N)

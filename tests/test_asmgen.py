@@ -16,6 +16,13 @@ def test_generated_loop_equals_oracle_in_the_emulator(oracle):
         assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_fair_variant_is_the_same_arithmetic_on_both_priority_paths(oracle):
+    for fair in ("0", "1"):     # partner never / always ahead
+        env = dict(os.environ, BR_FAIR=fair)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "6"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
 def test_stamped_variant_is_the_same_arithmetic(oracle):
     env = dict(os.environ, BR_STAMPS="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
@@ -32,8 +39,8 @@ def test_generated_trace_loop_equals_oracle_four_waves(oracle):
 def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])
-    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_clobbers.inc", "tx_trace_asm.inc", "tx_trace_asm_stamps.inc",
-              "tx_trace_asm_clobbers.inc"):
+    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_fair.inc", "tx_br_asm_fair_stamps.inc", "tx_br_asm_clobbers.inc",
+              "tx_trace_asm.inc", "tx_trace_asm_stamps.inc", "tx_trace_asm_clobbers.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 

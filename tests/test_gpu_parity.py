@@ -372,9 +372,11 @@ def test_trace_and_scheme_switch_ring_stress(rig256):
     assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
 
 
+@pytest.mark.parametrize("variant", ["4", "5"])
 @pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
-def test_two_wave_blind_rotation_kernel_bit_identical(which, request, monkeypatch):
-    """k_blind_rotate4 (generated assembly, csrc/tx_br_asm.inc) forced on a small launch: equals the oracle"""
+def test_two_wave_blind_rotation_kernel_bit_identical(which, variant, request, monkeypatch):
+    """k_blind_rotate4 / k_blind_rotate5 (generated assembly, csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair
+    arbitration) forced on a small launch: equals the oracle"""
     import txhip
     r = request.getfixturevalue(which)
     rng = np.random.default_rng(17)
@@ -383,7 +385,7 @@ def test_two_wave_blind_rotation_kernel_bit_identical(which, request, monkeypatc
     lwe[1, r.p.n] = np.uint64(2**64 - 1)        # body at the wrap-around
     lwe[2, :] = 0
     ref = r.octx.blind_rotate(lwe)
-    monkeypatch.setenv("TX_BR_VARIANT", "4")
+    monkeypatch.setenv("TX_BR_VARIANT", variant)
     e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)      # 13 units: a ragged last workgroup
     e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     got = e4.blind_rotate(lwe)
@@ -397,7 +399,7 @@ def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):
     import txhip
     r = rig256
     rng = np.random.default_rng(23)
-    cnt = 4 * 256 + 4 * 37 + 3                  # > 4 units per CU on a 256-CU chip, ragged
+    cnt = 8 * 256 + 8 * 37 + 3                  # > 4 units per CU on a 256-CU chip; persistent waves with 2 and 1 units, ragged
     lwe = rng.integers(0, 1 << 63, (cnt, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.p.n + 1), dtype=np.uint64)
     auto = r.eng.blind_rotate(lwe)
     monkeypatch.setenv("TX_BR_VARIANT", "0")

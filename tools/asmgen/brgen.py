@@ -21,6 +21,7 @@ Register map (VGPR):
     208..255 X  (key ring in the MAC; twiddles + spare quad in the transforms; body words in the rotation)
 SGPR: see `SG` below.  LDS image: tx_br2.hpp (twiddles at 0, per wave: 8 KiB unpadded tile + 8 KiB body).
 """
+import os
 import struct
 import sys
 from gcn import V, S, Lit, VCC, Prog
@@ -30,6 +31,7 @@ TWB = 15 * 64 * 16                      # byte offset of the compact pass-B twid
 
 # ---- register map
 LANE, L8T, L16T, L16, OFF1, TWBA, XHW, XLW, EREG, L8, R10, R11 = [V(i) for i in range(12)]
+PARTNER = V(9)      # fair mode: the partner wave's step counter, requested a step ahead (lane*8 lives here only in the epilogue)
 T0, T1 = V(12, 2), V(14, 2)
 A = [16, 48]
 D = [80, 112, 144]
@@ -44,6 +46,7 @@ class SG:
     NSTEP = S(40); I = S(41); TILE = S(42); ROT = S(43); CTV = S(44, 2); TMP = S(46); TMP2 = S(47)
     C_2M64 = S(48, 2); C_M2P64 = S(50, 2); C_84 = S(52, 2); C_52 = S(54, 2); C_SQH = S(56, 2); C_M4338 = S(58)
     KP0 = S(60, 2); KP1 = S(62, 2); KP2 = S(64, 2); KPN = S(66, 2)
+    FAIR = S(68); PROGA = S(69); PROGB = S(59); PBASE = S(67)   # fair mode: flag, LDS addresses of my / the partner's step counter, steps done before this unit
 
 
 def f64bits(x): return struct.unpack("<Q", struct.pack("<d", x))[0]
@@ -70,8 +73,16 @@ ST_PREV, ST_NOW, ST_DBG = S(82, 2), S(84, 2), S(86, 2)
 
 
 class Gen:
-    def __init__(self, stamps=False, prio="I"):
+    def __init__(self, stamps=False, prio="I", deep_prefetch=True, phase_stamps=True, fair=False):
         self.stamps = stamps
+        # fair: the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup) exchange their step counters
+        # through LDS every step; the one that is behind runs at a higher priority.  Without it the older wave wins
+        # every arbitration (25 k against 40 k cycles per step), finishes far ahead, and the younger one ends alone.
+        self.fair = fair
+        self.fair_h = int(os.environ.get("BR_FAIR_H", 8))
+        self.nlab = 0
+        self.deep_prefetch = deep_prefetch      # False: the 8-of-12 key prefetch of the first two-wave versions (experiments)
+        self.phase_stamps = phase_stamps        # False with stamps=True: only the clock marks at the start and the end of a unit
         # phases that run at s_setprio 1 ("R", "F", "M", "I", "U").  The single-polynomial inverse is the phase whose
         # exchange round trips nothing covers: a wave in it goes first when both waves of a SIMD have an instruction
         # ready (8192 units: 47.4-47.6 against 48.4-49.4 ms; MI the same, F / RU less)
@@ -100,7 +111,7 @@ class Gen:
         self.p.emit(op, *a, **kw)
         if op.startswith("ds_read"): self.lgq.append(self.regs(a[0]))
         elif op.startswith("ds_write"): self.lgq.append(set())
-        elif op == "s_memtime": self.lgq.append(set())
+        elif op in ("s_memtime", "s_memrealtime"): self.lgq.append(set())
         elif op.startswith("global_load_lds"): pass          # LDS-DMA: no destination register; the caller tags it
         elif op.startswith("global_load"): self.vmq.append(self.regs(a[0]))
         elif op.startswith("global_store"): self.vmq.append(set())
@@ -155,12 +166,64 @@ class Gen:
     def gstore(self, op, voff, src, sbase, offset=0): self.e(op, voff, src, sbase, offset=offset)
 
     def setprio(self, phase):
-        if self.prio: self.e("s_setprio", Lit(1 if phase in self.prio else 0))
+        hi = 1 if phase in self.prio else 0
+        if not self.fair:
+            if self.prio: self.e("s_setprio", Lit(hi))
+            return
+        # behind (FAIR != 0): priority 2 + phase bit; level or ahead: 0 + phase bit
+        self.nlab += 1
+        la, lb = "L_pa%d_%%=" % self.nlab, "L_pb%d_%%=" % self.nlab
+        self.e("s_cmp_lg_u32", SG.FAIR, Lit(0))
+        self.e("s_cbranch_scc1", la)
+        self.e("s_setprio", Lit(hi))
+        self.e("s_branch", lb)
+        self.p.label(la)
+        self.e("s_setprio", Lit(2 + hi))
+        self.p.label(lb)
+
+    def fair_exchange(self):
+        """step start: take the partner's counter requested a step ago, publish mine, request the next one"""
+        e = self.e
+        e("v_readfirstlane_b32", SG.TMP, PARTNER)                # e() waits for the pending ds_read
+        e("s_nop", Lit(3))
+        # hysteresis: priority flips rarely -- a wave that has fallen FAIR_H steps behind goes first until it has caught
+        # up; in between the hardware's own rule (oldest first) runs undisturbed, which is the efficient regime for a pair
+        e("s_add_u32", SG.TMP2, SG.PBASE, SG.I)                  # steps this wave has done since the kernel started
+        e("s_sub_u32", SG.TMP, SG.TMP, SG.TMP2)                  # partner - me (as a signed number)
+        self.nlab += 1
+        l_set, l_end = "L_fs%d_%%=" % self.nlab, "L_fe%d_%%=" % self.nlab
+        e("s_cmp_lg_u32", SG.FAIR, Lit(0))
+        e("s_cbranch_scc0", l_set)
+        e("s_cmp_gt_i32", SG.TMP, Lit(0))                        # still behind? keep the priority
+        e("s_cbranch_scc1", l_end)
+        e("s_mov_b32", SG.FAIR, Lit(0))
+        e("s_branch", l_end)
+        self.p.label(l_set)
+        e("s_cmp_gt_i32", SG.TMP, Lit(self.fair_h))
+        e("s_cbranch_scc0", l_end)
+        e("s_mov_b32", SG.FAIR, Lit(1))
+        self.p.label(l_end)
+        e("v_mov_b32", T0.lo(), SG.TMP2)
+        e("v_mov_b32", T0.hi(), SG.PROGA)
+        e("ds_write_b32", T0.hi(), T0.lo(), offset=0)
+        e("v_mov_b32", T1.lo(), SG.PROGB)
+        e("ds_read_b32", PARTNER, T1.lo(), offset=0)
+
+    def clock_mark(self, slot):
+        """diagnostic build: s_memtime and s_memrealtime (100 MHz) to dbg[slot], dbg[slot + 1]: the host derives the shader clock"""
+        e = self.e
+        self.lg_wait_all()
+        for k, op in enumerate(("s_memtime", "s_memrealtime")):
+            e(op, ST_NOW)
+            self.lg_wait_all()
+            e("v_mov_b32", T0.hi(), Lit(0))
+            e("v_mov_b32", T1.lo(), ST_NOW.lo()); e("v_mov_b32", T1.hi(), ST_NOW.hi())
+            e("global_store_dwordx2", T0.hi(), T1, ST_DBG, offset=8 * (slot + k))
 
     def stamp(self, k):
         """diagnostic build only: cycles since the previous stamp are added to accumulator k (s_memtime returns
         through lgkmcnt, so the LDS queue is drained first: the stamps perturb what they measure)"""
-        if not self.stamps: return
+        if not self.stamps or not self.phase_stamps: return
         self.lg_wait_all()
         self.e("s_memtime", ST_NOW)
         self.lg_wait_all()
@@ -456,7 +519,10 @@ class Gen:
         e("v_or_b32", XLW, XLW, T1.hi())
         e("v_and_b32", T0.lo(), Lit(1), LANE)
         e("v_sub_u32", EREG, Lit(1), T0.lo())
-        e("v_lshlrev_b32", L8, Lit(3), LANE)
+        if self.fair:
+            e("v_mov_b32", PARTNER, Lit(0))
+            e("s_mov_b32", SG.FAIR, Lit(0))
+        else: e("v_lshlrev_b32", L8, Lit(3), LANE)
         for name, val in (("C_2M64", 2.0 ** -64), ("C_M2P64", -(2.0 ** 64)), ("C_84", 1.5 * 2.0 ** 84), ("C_52", 1.5 * 2.0 ** 52),
                           ("C_SQH", 0.70710678118654752440)):
             s, b = getattr(SG, name), f64bits(val)
@@ -470,12 +536,14 @@ class Gen:
         if self.stamps:
             for k in range(NSTAMP):
                 e("s_mov_b32", ST_ACC[k].lo(), Lit(0)); e("s_mov_b32", ST_ACC[k].hi(), Lit(0))
+            self.clock_mark(8)
             self.stamp(None)
 
     def step(self):
         e = self.e
         self.p.label("L_step%=")
         # ---- rotation amount of this step (wave-uniform), prefetch of the next mask element
+        if self.fair: self.fair_exchange()
         self.setprio("R")
         self.c("---- modswitch(ct[i]) -> rot; base = (lane - rot) mod 2N")
         # loop head: the only vector-memory operation that can be in flight is the load of this step's mask element
@@ -509,6 +577,34 @@ class Gen:
         e("s_lshl_b32", SG.TMP, SG.TMP, Lit(3))
         e("v_mov_b32", R10, SG.TMP)
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)
+        NG = 12
+        # Key ring: 12 register quads (X).  Eleven of a column's first twelve elements are issued ahead of the MAC, into
+        # the quads that are free at the time: column 0 -- X9..11 at the start of the step (the rotation uses X0..7 only),
+        # X0..7 before the last forward pass (twiddles done), X8 (the spare) at the MAC; columns 1, 2 -- X1..11 right
+        # after the previous inverse (the conversions then run two chains on X0, T0, T1), X0 at the MAC.
+        EARLY = 11 if self.deep_prefetch else 8
+        stream = [(q, r) for q in range(3) for r in range(8)]
+        kps = (SG.KP0, SG.KP1, SG.KP2)
+
+        def ring_of(col):      # slot order = consumption order = issue order
+            if self.deep_prefetch: order = [9, 10, 11, 0, 1, 2, 3, 4, 5, 6, 7, 8] if col == 0 else [4, 5, 6, 7, 8, 9, 10, 11, 1, 2, 3, 0]
+            else: order = list(range(12)) if col == 0 else list(range(4, 12)) + list(range(4))
+            return [quad(X, r) for r in order]
+
+        def key_ptrs(col):
+            for q in range(3):
+                e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
+                e("s_addc_u32", kps[q].hi(), SG.ROW.hi(), Lit(0))
+
+        def issue(col, k):
+            q, r = stream[k]
+            self.gload("global_load_dwordx4", ring_of(col)[k % NG], L16 if r < 4 else OFF1, kps[q], offset=(r & 3) * 1024)
+
+        def early(col, lo=0, hi=EARLY):
+            self.c("key ring: elements %d..%d of column %d, issued ahead of their use" % (lo, hi - 1, col))
+            if lo == 0: key_ptrs(col)
+            for k in range(lo, hi): issue(col, k)
+        if self.deep_prefetch: early(0, 0, 3)                  # X9..11: free for the whole rotation / forward phase
         # ---- stage the mask polynomials through the tile, gather the rotated words (in-order LDS: no waits in between)
         self.c("---- rotation: stage mask polynomials in the tile, gather rotated coefficients")
         xq = [quad(X, r) for r in range(12)]
@@ -544,30 +640,9 @@ class Gen:
         digits(2)
         self.stamp(0)
         # ---- forward transforms
-        NG, EARLY = 12, 8
-        stream = [(q, r) for q in range(3) for r in range(8)]
-        kps = (SG.KP0, SG.KP1, SG.KP2)
-
-        def ring_of(col):      # the first EARLY slots are the quads that are free when they are issued
-            order = list(range(12)) if col == 0 else list(range(4, 12)) + list(range(4))
-            return [quad(X, r) for r in order]
-
-        def key_ptrs(col):
-            for q in range(3):
-                e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
-                e("s_addc_u32", kps[q].hi(), SG.ROW.hi(), Lit(0))
-
-        def issue(col, k):
-            q, r = stream[k]
-            self.gload("global_load_dwordx4", ring_of(col)[k % NG], L16 if r < 4 else OFF1, kps[q], offset=(r & 3) * 1024)
-
-        def early(col):
-            self.c("key ring: first %d elements of column %d, issued ahead of their use" % (EARLY, col))
-            key_ptrs(col)
-            for k in range(EARLY): issue(col, k)
         polys = [[quad(D[p], r) for r in range(8)] for p in range(3)]
         self.setprio("F")
-        polys, spare = self.fwd3(polys, xq, before_pass3=lambda: early(0))
+        polys, spare = self.fwd3(polys, xq, before_pass3=lambda: early(0, 3 if self.deep_prefetch else 0, EARLY))
         self.stamp(1)
         # ---- per column: multiply-accumulate against the key, inverse transform, update
         for col in range(3):
@@ -597,7 +672,10 @@ class Gen:
             self.setprio("U")
             if col < 2: early(col + 1)              # lands during the conversions below (they use X[0..3] only)
             self.c("---- column %d: accumulator += round(inverse)" % col)
-            tmp = [(V(X + 4 * k, 2), V(X + 4 * k + 2, 2)) for k in range(4)]     # X[0..3]: free again after the inverse
+            # conversions: columns 0, 1 run two chains (temporaries X0, T0, T1: X1..11 already hold the next column's keys),
+            # column 2 four (X0..3; nothing is prefetched behind it)
+            nch = 4 if (col == 2 or not self.deep_prefetch) else 2
+            tmp = [(V(X + 4 * k, 2), V(X + 4 * k + 2, 2)) for k in range(4)] if nch == 4 else [(V(X, 2), V(X + 2, 2)), (T0, T1)]
             CUR = [V(X + 16 + 2 * j, 2) for j in range(16)]                      # body words (column 2): X[4..11]
             if col == 2:
                 for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=8192 + 512 * j)
@@ -615,7 +693,7 @@ class Gen:
             for m in range(8):
                 for half in range(2):
                     chains.append(self.chain(upd, m, half, len(chains)))
-                    if len(chains) == 4:
+                    if len(chains) == nch:
                         self.merge(chains); chains = []
             self.stamp(4)
         # ---- loop control
@@ -631,6 +709,14 @@ class Gen:
         e = self.e
         self.c("---- epilogue: store the accumulator")
         self.vm_wait_all()
+        if self.fair:
+            self.lg_wait_all()
+            e("s_setprio", Lit(0))
+            e("s_add_u32", SG.TMP2, SG.PBASE, SG.NSTEP)          # this unit is done (the wrapper publishes "finished" after its last one)
+            e("v_mov_b32", T0.lo(), SG.TMP2)
+            e("v_mov_b32", T0.hi(), SG.PROGA)
+            e("ds_write_b32", T0.hi(), T0.lo(), offset=0)
+            e("v_lshlrev_b32", L8, Lit(3), LANE)
         e("v_add_u32", T0.lo(), Lit(4096), L8)
         for q in range(3):
             e("s_add_u32", SG.KP0.lo(), SG.OUT.lo(), Lit(q * 8192))
@@ -648,6 +734,7 @@ class Gen:
             for k in range(NSTAMP):
                 e("v_mov_b32", T1.lo(), ST_ACC[k].lo()); e("v_mov_b32", T1.hi(), ST_ACC[k].hi())
                 self.gstore("global_store_dwordx2", T0.hi(), T1, ST_DBG, offset=8 * k)
+            self.clock_mark(10)
             self.vm_wait_all()
 
     def build(self):
@@ -660,11 +747,15 @@ class Gen:
 INPUTS = ["ct", "row", "out", "n", "tile"]     # asm operands %0..%4 ("s" constraints)
 
 
-def render_inc(prog, stamps=False):
-    """C string literal pieces of ONE asm block.  Operand copies first: %0 ct (64), %1 bsk row 0 (64), %2 out (64), %3 n, %4 tile base"""
+def render_inc(prog, stamps=False, fair=False):
+    """C string literal pieces of ONE asm block.  Operand copies first: %0 ct (64), %1 bsk row 0 (64), %2 out (64), %3 n, %4 tile base,
+    fair: %5 / %6 LDS addresses of this wave's / its SIMD partner's step counter, %7 steps done before this unit; stamps: then the debug buffer (64)"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
             "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE]
-    if stamps: head.append("s_mov_b64 %s, %%5" % ST_DBG)
+    nop = 5
+    if fair:
+        head += ["s_mov_b32 %s, %%5" % SG.PROGA, "s_mov_b32 %s, %%6" % SG.PROGB, "s_mov_b32 %s, %%7" % SG.PBASE]; nop = 8
+    if stamps: head.append("s_mov_b64 %s, %%%d" % (ST_DBG, nop))
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen.py -- do not edit"]
     for l in lines:
@@ -679,12 +770,16 @@ def render_clobbers():
 
 if __name__ == "__main__":
     import os as _os
-    g = Gen(prio=_os.environ.get("BR_PRIO", "I"))
+    g = Gen(prio=_os.environ.get("BR_PRIO", "I"), deep_prefetch=_os.environ.get("BR_EARLY", "11") != "8")
     prog = g.build()
     if len(sys.argv) > 2 and sys.argv[1] == "--out":
         import os
         open(os.path.join(sys.argv[2], "tx_br_asm.inc"), "w").write(render_inc(prog))
-        open(os.path.join(sys.argv[2], "tx_br_asm_stamps.inc"), "w").write(render_inc(Gen(stamps=True).build(), stamps=True))
+        open(os.path.join(sys.argv[2], "tx_br_asm_fair.inc"), "w").write(render_inc(Gen(prio=_os.environ.get("BR_PRIO", "I"), fair=True).build(), fair=True))
+        open(os.path.join(sys.argv[2], "tx_br_asm_fair_stamps.inc"), "w").write(render_inc(
+            Gen(stamps=True, fair=True, phase_stamps=not _os.environ.get("BR_CLOCK_ONLY")).build(), stamps=True, fair=True))
+        open(os.path.join(sys.argv[2], "tx_br_asm_stamps.inc"), "w").write(render_inc(Gen(stamps=True, deep_prefetch=_os.environ.get("BR_EARLY", "11") != "8",
+                                                                                           phase_stamps=not _os.environ.get("BR_CLOCK_ONLY")).build(), stamps=True))
         open(os.path.join(sys.argv[2], "tx_br_asm_clobbers.inc"), "w").write(render_clobbers())
     elif len(sys.argv) > 1 and sys.argv[1] == "--count":
         c = prog.count()

@@ -274,11 +274,22 @@ class Emu:
         self.nclk = getattr(self, "nclk", 0) + 1000
         def apply(v=self.nclk, i=d.i): self.s[i] = v & 0xFFFFFFFF; self.s[i + 1] = v >> 32
         self.lgq.append(([], apply))
+    def op_s_memrealtime(self, d):
+        self.nrt = getattr(self, "nrt", 0) + 40
+        def apply(v=self.nrt, i=d.i): self.s[i] = v & 0xFFFFFFFF; self.s[i + 1] = v >> 32
+        self.lgq.append(([], apply))
     def op_s_lshr_b32(self, d, a, b): self.s[d.i] = self.sval(a) >> (self.sval(b) & 31)
     def op_s_lshl_b32(self, d, a, b): self.s[d.i] = (self.sval(a) << (self.sval(b) & 31)) & 0xFFFFFFFF
     def op_s_and_b32(self, d, a, b): self.s[d.i] = self.sval(a) & self.sval(b)
     def op_s_cmp_lt_u32(self, a, b): self.scc = self.sval(a) < self.sval(b)
     def op_s_cbranch_scc1(self, lab): return lab if self.scc else None
+    def op_s_cbranch_scc0(self, lab): return None if self.scc else lab
+    def op_s_branch(self, lab): return lab
+    def op_s_cmp_lg_u32(self, a, b): self.scc = self.sval(a) != self.sval(b)
+    def op_s_cmp_gt_i32(self, a, b):
+        x, y = self.sval(a), self.sval(b)
+        x = x - (1 << 32) if x >> 31 else x; y = y - (1 << 32) if y >> 31 else y
+        self.scc = x > y
     def op_s_mul_i32(self, d, a, b): self.s[d.i] = (self.sval(a) * self.sval(b)) & 0xFFFFFFFF
     def op_s_nop(self, n): pass
     def op_s_setprio(self, n): pass

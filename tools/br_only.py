@@ -25,9 +25,41 @@ if hasattr(txhip.lib(), "tx_debug_stamps"):        # -DTXD_STAMPS build: cycles 
     names = ["rotate+decompose", "forward x3", "MAC", "inverse x3", "convert+update"]
     steps = max(1, st[6])
     print("stamps (cycles/step):", {n: round(st[i] / steps) for i, n in enumerate(names)}, "sum", round(sum(st[:5]) / steps))
+    print("raw stamps 8..11:", [int(st[k]) for k in range(8, 12)])
+    if st[10] > st[8] and st[11] > st[9]:      # generated loop: s_memtime / s_memrealtime (100 MHz) at the start and the end of the unit
+        print("shader clock of that wave: %.3f GHz over %.2f ms" % ((st[10] - st[8]) / (st[11] - st[9]) * 0.1, (st[11] - st[9]) * 1e-5))
     print("inside forward x3:", {n: round(st[8 + i] / steps) for i, n in enumerate(["twist", "dft8+tw+xchg_hi", "dft8+tw+xchg_lo", "dft8"])})
 if len(sys.argv) > 4:
     acc = rnd(count // 8 * 3072).reshape(-1, 3, 1024)
     for r in range(reps):
         eng.extract_trace(acc)
         print("extract_trace", acc.shape[0] * 7, "units:", round(eng.timing()["ms_trace"], 3), "ms", flush=True)
+if hasattr(txhip.lib(), "tx_debug_wave_times") and os.environ.get("TX_BR_VARIANT", "4") == "4":
+    nw = min(4096, count // 4)
+    buf = (C.c_ulonglong * (2 * nw))()
+    txhip.lib().tx_debug_wave_times(C.c_void_p(eng.h), buf, 2 * nw)
+    a = np.array(buf[:], np.uint64).reshape(-1, 2).astype(np.int64)
+    a = a[a[:, 1] > a[:, 0]]
+    t0 = a[:, 0].min()
+    life = (a[:, 1] - a[:, 0]) * 1e-5; end = (a[:, 1] - t0) * 1e-5; start = (a[:, 0] - t0) * 1e-5
+    print("workgroups %d: lifetime min/median/max %.2f / %.2f / %.2f ms; last start %.2f ms, last end %.2f ms" % (a.shape[0], life.min(), np.median(life), life.max(), start.max(), end.max()))
+    h, edges = np.histogram(start, bins=np.arange(0, end.max() + 2, 2.0))
+    print("starts per 2 ms:", h.tolist())
+    h, edges = np.histogram(end, bins=np.arange(0, end.max() + 2, 2.0))
+    print("ends per 2 ms:  ", h.tolist())
+    print("lifetime by start time (2 ms bins):", [round(float(np.median(life[(start >= lo) & (start < lo + 2)])), 2) if ((start >= lo) & (start < lo + 2)).any() else None for lo in np.arange(0, start.max() + 2, 2.0)])
+if hasattr(txhip.lib(), "tx_debug_wave_times") and os.environ.get("TX_BR_VARIANT") == "5":
+    nw = min(2048, (count + 0))
+    buf = (C.c_ulonglong * (2 * nw))()
+    txhip.lib().tx_debug_wave_times(C.c_void_p(eng.h), buf, 2 * nw)
+    a = np.array(buf[:], np.uint64).reshape(-1, 2).astype(np.int64)
+    a = a[a[:, 1] > a[:, 0]]
+    t0 = a[:, 0].min()
+    life = (a[:, 1] - a[:, 0]) * 1e-5; end = (a[:, 1] - t0) * 1e-5; start = (a[:, 0] - t0) * 1e-5
+    print("waves %d: start max %.3f ms; lifetime min/median/max %.2f / %.2f / %.2f ms; end min/median/max %.2f / %.2f / %.2f ms" %
+          (a.shape[0], start.max(), life.min(), np.median(life), life.max(), end.min(), np.median(end), end.max()))
+    # by CU (8 consecutive wave slots) and by SIMD pair
+    cu = end.reshape(-1, 8) if end.size % 8 == 0 else None
+    if cu is not None:
+        print("per workgroup: max-min of its 8 waves' end times: median %.2f ms, max %.2f ms; workgroup end time min/median/max %.2f / %.2f / %.2f" %
+              (np.median(cu.max(1) - cu.min(1)), (cu.max(1) - cu.min(1)).max(), cu.max(1).min(), np.median(cu.max(1)), cu.max(1).max()))
