@@ -67,6 +67,7 @@ class Cx:
 
 
 CARRY = [S(88, 2), S(90, 2), S(92, 2), S(94, 2)]      # one carry mask per interleaved integer chain (VOP3 carry operands)
+ABL = os.environ.get("BR_ABL", "")      # timing-only ablations (K keys, X exchanges, T twiddle loads, M MAC arithmetic): outputs invalid
 NSTAMP = 6
 ST_ACC = [S(70 + 2 * k, 2) for k in range(NSTAMP)]
 ST_PREV, ST_NOW, ST_DBG = S(82, 2), S(84, 2), S(86, 2)
@@ -162,7 +163,9 @@ class Gen:
 
     def ds_read(self, op, d, addr, offset=0): self.e(op, d, addr, offset=offset)
     def ds_write(self, op, addr, src, offset=0): self.e(op, addr, src, offset=offset)
-    def gload(self, op, d, voff, sbase, offset=0): self.e(op, d, voff, sbase, offset=offset)
+    def gload(self, op, d, voff, sbase, offset=0):
+        if "K" in ABL and op == "global_load_dwordx4": return          # timing experiment: results are garbage
+        self.e(op, d, voff, sbase, offset=offset)
     def gstore(self, op, voff, src, sbase, offset=0): self.e(op, voff, src, sbase, offset=offset)
 
     def setprio(self, phase):
@@ -343,9 +346,11 @@ class Gen:
 
     # ---------------------------------------------------------------- LDS tile exchanges (unpadded, tx_br2.hpp)
     def xchg_hi_write(self, v):
+        if "X" in ABL: return
         for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
 
     def xchg_read(self, dst, swz):
+        if "X" in ABL: return
         for r in range(8):
             if swz:
                 self.e("v_xor_b32", T1.lo(), Lit(r << 4), L16T)
@@ -354,12 +359,14 @@ class Gen:
                 self.ds_read("ds_read_b128", dst[r], L16T, offset=1024 * r)
 
     def xchg_lo_write(self, v):
+        if "X" in ABL: return
         for r in range(8):
             self.e("v_xor_b32", T1.lo(), Lit(r << 4), XLW)
             self.ds_write("ds_write_b128", T1.lo(), v[r], offset=0)
 
     def load_tw(self, dst, row0, nrows, compact=False):
         """twiddle rows row0.. into quads dst[0..nrows-1]"""
+        if "T" in ABL: return
         for k in range(nrows):
             if compact: self.ds_read("ds_read_b128", dst[k], TWBA, offset=128 * k)
             else: self.ds_read("ds_read_b128", dst[k], L16, offset=1024 * (row0 + k))
@@ -653,6 +660,7 @@ class Gen:
             Fq = [quad(F, r) for r in range(8)]
 
             def mac(k):
+                if "M" in ABL: return
                 q, r = stream[k]
                 g, d = ring[k % NG], polys[q][r]
                 re0 = Lit(0, f64=0.0) if q == 0 else qre(Fq[r])
