@@ -23,9 +23,11 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # HBM-side traffic of ONE blind-rotation launch over 8192 units (medium on one GPU), from separate rocprofv3 --pmc
 # passes: FETCH_SIZE x 2 (gfx950 counts half of a 16 B/lane streaming read, MI355X_MICROARCH.md HBM) + WRITE_SIZE.
 # The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident batch of waves, mostly from the
-# Infinity Cache.  k_blind_rotate4 (two waves per SIMD, the kernel that runs above 4 units per CU):
-# profiles/r2_final_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
-BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": None, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024, "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
+# Infinity Cache.  k_blind_rotate5 (two waves per SIMD, persistent; runs above 4 units per CU):
+# profiles/r2_final_pmc_{fetch,write}_size_blind_rotate5.csv (each XCD streams the key 4 times, once per unit of a wave);
+# k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
+BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (1028895 * 2 + 208384) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
+                         "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
 # per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
 # compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)

@@ -710,6 +710,7 @@ class Gen:
         e("s_addc_u32", SG.ROW.hi(), SG.ROW.hi(), Lit(0))
         e("s_add_u32", SG.I, SG.I, Lit(1))
         e("s_cmp_lt_u32", SG.I, SG.NSTEP)
+        if "K" in ABL: self.vm_wait_all()
         assert self.vmq == [] and self.lgq == [], (self.vmq, self.lgq)      # same state as at the loop head
         e("s_cbranch_scc1", "L_step%=")
 
