@@ -347,7 +347,7 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     // 512 registers) is the faster one (1024 units: 8.0 against 8.5 ms; 8192 units: 59.7 against 46.6 ms).
     const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 5 : 0);
     if (variant == 5) {
-        size_t wgs = std::min<size_t>((count + BR5_WAVES - 1) / BR5_WAVES, (size_t)c->num_cus);     // persistent, one per CU
+        size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
         if (const char *e = getenv("TX_BR5_WGS")) wgs = std::min<size_t>(wgs, (size_t)std::max(1, atoi(e)));      // experiments only
         hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc,
                            (int)count, (int)c->p.n, c->bsk_f, c->tw);

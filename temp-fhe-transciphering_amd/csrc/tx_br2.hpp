@@ -374,9 +374,11 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 constexpr int BR5_WAVES = 8;
 constexpr size_t LDS_BYTES_BR5 = BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WAVE_BYTES + BR5_WAVES * sizeof(uint32_t);
 
-// Persistent: `gridDim.x` workgroups (one per CU), wave w of workgroup b takes units b * 8 + w + k * 8 * gridDim.x,
-// k = 0, 1, ... -- a static share, so that no wave picks up an extra 11 ms unit at the end; the step counters keep
-// counting across units.  A wave leaves when its share is done (it then reads as "finished" to its partner).
+// Persistent: G = gridDim.x workgroups (one per CU), wave w of workgroup b takes units w * G + b + k * 8 G, k = 0, 1, ...
+// -- a static share, so that no wave picks up an extra 11 ms unit at the end, and wave-major, so that a launch that
+// does not fill every wave still spreads over every CU (the first G units go to wave 0 of every workgroup, the next G
+// to wave 1, ...; waves 0-3 sit on the four SIMDs, waves 4-7 double them up).  The step counters keep counting
+// across units.  A wave leaves when its share is done (it then reads as "finished" to its partner).
 __global__ __launch_bounds__(512, 2)
 void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
 {
@@ -386,7 +388,7 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
     if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int first = blockIdx.x * BR5_WAVES + wave, stride = (int)gridDim.x * BR5_WAVES;
+    const int first = wave * (int)gridDim.x + (int)blockIdx.x, stride = (int)gridDim.x * BR5_WAVES;
     // a wave without a unit is "finished" from the start: its partner is never behind it
     if ((threadIdx.x & 63) == 0) prog[wave] = (first < count) ? 0u : 0xFFFFFFFFu;
     __syncthreads();
