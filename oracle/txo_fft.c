@@ -73,7 +73,11 @@ static inline void dft8(cplx v[8], int s)
 }
 
 /* ---------------- tables ---------------- */
-static cplx TW1024[22][64];      /* rows 0-7 twist (j = lane + 64 row), 8-14 pass A (k1=1..7), 15-21 pass B (c=1..7) */
+/* The twist e^{i pi j/1024}, j = 64 n1 + n2, is split: its n1 part C16[n1] = e^{i pi n1/16} multiplies the
+ * inputs of pass A (eight constants, no table), its n2 part is folded into the pass-A twiddles:
+ * rows 0-7: e^{i pi n2 (1 + 4 k1)/1024} (k1 = 0..7); rows 8-14: pass B (c = 1..7). */
+static cplx TW1024[15][64];
+static cplx C16[8];
 static int  tables_ready = 0;
 
 typedef struct { uint32_t N; cplx *twist; cplx *w; } small_tab;   /* generic radix-2 tables */
@@ -92,15 +96,15 @@ static cplx unit(long double num, long double den)
 static void build_tables(void)
 {
     if (tables_ready) return;
-    for (int m = 0; m < 8; m++)
-        for (int t = 0; t < 64; t++) TW1024[m][t] = unit(t + 64 * m, 1024);
-    for (int k1 = 1; k1 < 8; k1++)
-        for (int t = 0; t < 64; t++) TW1024[7 + k1][t] = unit(2 * (t * k1), 512);
+    for (int m = 0; m < 8; m++) C16[m] = unit(m, 16);
+    for (int k1 = 0; k1 < 8; k1++)
+        for (int t = 0; t < 64; t++) TW1024[k1][t] = unit(t * (1 + 4 * k1), 1024);
     for (int c = 1; c < 8; c++)
-        for (int t = 0; t < 64; t++) TW1024[14 + c][t] = unit(2 * ((t & 7) * c), 64);
+        for (int t = 0; t < 64; t++) TW1024[7 + c][t] = unit(2 * ((t & 7) * c), 64);
     tables_ready = 1;
 }
 const double *txo_twiddles_1024(void) { build_tables(); return (const double *)TW1024; }
+const double *txo_twist_consts_1024(void) { build_tables(); return (const double *)C16; }
 
 static const small_tab *small_tables(uint32_t N)
 {
@@ -118,17 +122,15 @@ static const small_tab *small_tables(uint32_t N)
 static void fwd1024(const double *a, cplx *out)
 {
     cplx c[512], z[512];
-    for (int j = 0; j < 512; j++) {
-        cplx x = { a[j], a[j + 512] };
-        c[j] = cmul(x, TW1024[j >> 6][j & 63]);
-    }
     /* pass A: lane n2, regs n1 -> k1 */
     for (int n2 = 0; n2 < 64; n2++) {
         cplx v[8];
-        for (int n1 = 0; n1 < 8; n1++) v[n1] = c[64 * n1 + n2];
+        for (int n1 = 0; n1 < 8; n1++) {
+            cplx x = { a[64 * n1 + n2], a[64 * n1 + n2 + 512] };
+            v[n1] = n1 ? cmul(x, C16[n1]) : x;
+        }
         dft8(v, +1);
-        for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul(v[k1], TW1024[7 + k1][n2]);
-        for (int k1 = 0; k1 < 8; k1++) z[k1 * 64 + n2] = v[k1];
+        for (int k1 = 0; k1 < 8; k1++) z[k1 * 64 + n2] = cmul(v[k1], TW1024[k1][n2]);
     }
     /* pass B: lane (k1,b), regs a -> c */
     for (int k1 = 0; k1 < 8; k1++)
@@ -136,7 +138,7 @@ static void fwd1024(const double *a, cplx *out)
             cplx v[8];
             for (int a8 = 0; a8 < 8; a8++) v[a8] = z[k1 * 64 + 8 * a8 + b];
             dft8(v, +1);
-            for (int cc = 1; cc < 8; cc++) v[cc] = cmul(v[cc], TW1024[14 + cc][b]);
+            for (int cc = 1; cc < 8; cc++) v[cc] = cmul(v[cc], TW1024[7 + cc][b]);
             for (int cc = 0; cc < 8; cc++) c[k1 * 64 + b * 8 + cc] = v[cc];   /* y[k1][b][c] */
         }
     /* pass C: lane (k1,c), regs b -> d */
@@ -163,18 +165,17 @@ static void inv1024(const cplx *in, double *a)
         for (int b = 0; b < 8; b++) {
             cplx v[8];
             v[0] = y[k1 * 64 + b * 8];
-            for (int cc = 1; cc < 8; cc++) v[cc] = cmulc(y[k1 * 64 + b * 8 + cc], TW1024[14 + cc][b]);
+            for (int cc = 1; cc < 8; cc++) v[cc] = cmulc(y[k1 * 64 + b * 8 + cc], TW1024[7 + cc][b]);
             dft8(v, -1);
             for (int a8 = 0; a8 < 8; a8++) z[k1 * 64 + 8 * a8 + b] = v[a8];
         }
     for (int n2 = 0; n2 < 64; n2++) {
         cplx v[8];
-        v[0] = z[n2];
-        for (int k1 = 1; k1 < 8; k1++) v[k1] = cmulc(z[k1 * 64 + n2], TW1024[7 + k1][n2]);
+        for (int k1 = 0; k1 < 8; k1++) v[k1] = cmulc(z[k1 * 64 + n2], TW1024[k1][n2]);
         dft8(v, -1);
         for (int n1 = 0; n1 < 8; n1++) {
             int j = 64 * n1 + n2;
-            cplx r = cmulc(v[n1], TW1024[j >> 6][j & 63]);
+            cplx r = n1 ? cmulc(v[n1], C16[n1]) : v[n1];
             a[j] = r.re; a[j + 512] = r.im;
         }
     }

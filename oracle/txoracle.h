@@ -175,8 +175,10 @@ void txo_aes128_expand(const uint8_t key[16], uint8_t rk[11][16]);
 void txo_aes128_encrypt_block(const uint8_t rk[11][16], const uint8_t in[16], uint8_t out[16]);
 void txo_aes128_decrypt_block(const uint8_t rk[11][16], const uint8_t in[16], uint8_t out[16]);
 /* the twiddle tables, for cross-checking the product's tables: returns pointer to
- * [22][64] complex for N=1024 (8 twist, 7 pass-A, 7 pass-B rows) */
+ * [15][64] complex for N=1024 (8 pass-A rows with the lane part of the twist folded in, 7 pass-B rows);
+ * txo_twist_consts_1024: the eight constants e^{i pi n1/16} of the twist's register part */
 const double *txo_twiddles_1024(void);
+const double *txo_twist_consts_1024(void);
 
 #ifdef __cplusplus
 }

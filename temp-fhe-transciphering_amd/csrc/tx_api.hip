@@ -78,12 +78,10 @@ static cplx unit_root(long double num, long double den)
 static int upload_tables(tx_ctx *c)
 {
     std::vector<cplx> tw(TW_ROWS * 64), t2(192);
-    for (int m = 0; m < 8; m++)
-        for (int t = 0; t < 64; t++) tw[m * 64 + t] = unit_root(t + 64 * m, 1024);
+    for (int r = 0; r < 8; r++)         // pass A with the lane part of the twist: exp(i pi t (1 + 4 r) / 1024)
+        for (int t = 0; t < 64; t++) tw[r * 64 + t] = unit_root(t * (1 + 4 * r), 1024);
     for (int r = 1; r < 8; r++)
-        for (int t = 0; t < 64; t++) tw[(7 + r) * 64 + t] = unit_root(2 * (t * r), 512);
-    for (int r = 1; r < 8; r++)
-        for (int t = 0; t < 64; t++) tw[(14 + r) * 64 + t] = unit_root(2 * ((t & 7) * r), 64);
+        for (int t = 0; t < 64; t++) tw[(7 + r) * 64 + t] = unit_root(2 * ((t & 7) * r), 64);
     for (int j = 0; j < 128; j++) t2[j] = unit_root(j, 256);
     for (int j = 0; j < 64; j++) t2[128 + j] = unit_root(2 * j, 128);
     HIP_OK(hipMalloc(&c->tw, tw.size() * sizeof(cplx)));

@@ -24,22 +24,22 @@
 namespace txd {
 
 // ---- LDS image of this kernel: 2 workgroups of 256 threads per CU, 80 KiB each ----
-//   twist 8 rows + pass-A 7 rows of 64 complex (as tx_device.hpp), pass-B 7 rows of EIGHT complex (the pass-B
-//   twiddle depends on lane & 7 only): 16 256 B; then per wave an UNPADDED 8 KiB transpose tile and the 8 KiB body.
-//   16 256 + 4 x 16 384 = 81 792 B <= 81 920 B.  The pitch-65 padding of tx_device.hpp (512 B per workgroup) would
+//   pass-A 8 rows of 64 complex (as tx_device.hpp), pass-B 7 rows of EIGHT complex (the pass-B twiddle depends on
+//   lane & 7 only): 9 088 B; then per wave an UNPADDED 8 KiB transpose tile and the 8 KiB body.
+//   9 088 + 4 x 16 384 = 74 624 B <= 81 920 B.  The pitch-65 padding of tx_device.hpp (512 B per workgroup) would
 //   not fit, so the second exchange stores column (8g + r) ^ b of row b instead (XOR swizzle): 8 consecutive lanes
 //   of a ds_write_b128 still hit 8 distinct bank quads, and a ds_read_b128 reads lane ^ r', a permutation inside
 //   aligned groups of 8 columns, which keeps its 16-lane groups on 16 distinct quads.  The first exchange needs no
 //   skew at all: its 8-lane store groups are contiguous 128-byte runs.
-constexpr int BR3_TWB = 15 * 64;                             // first pass-B entry (complex units)
-constexpr int BR3_TW_CPLX = 15 * 64 + 7 * 8;
+constexpr int BR3_TWB = 8 * 64;                              // first pass-B entry (complex units)
+constexpr int BR3_TW_CPLX = 8 * 64 + 7 * 8;
 constexpr size_t BR3_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)N * sizeof(uint64_t);
 constexpr size_t LDS_BYTES_BR3 = BR3_TW_CPLX * sizeof(cplx) + WAVES * BR3_WAVE_BYTES;
 static_assert(LDS_BYTES_BR3 <= 80 * 1024, "two workgroups per CU");
 
 #ifdef TXD_WITH_BR3   // the hipcc version of this layout: readable specification of the generated loop, not built by default
 struct Br3Ctx {
-    const cplx *tw;     // twist rows 0..7, pass-A rows 8..14 (row 7 + r), pass-B compact at BR3_TWB
+    const cplx *tw;     // pass-A rows 0..7, pass-B compact at BR3_TWB
     cplx *tile;         // 512 complex, unpadded
     uint64_t *pl;       // the tile as 1024 torus words
     uint64_t *bl;       // body polynomial
@@ -73,10 +73,10 @@ __device__ __forceinline__ void fft_fwd_s(cplx (&v)[8], const Br3Ctx &w)
 {
     const int lane = w.lane;
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = cmul(v[m], w.tw[m * 64 + lane]);
+    for (int m = 1; m < 8; m++) v[m] = cmul(v[m], c16(m));
     dft8<+1>(v);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w.tw[(7 + r) * 64 + lane]);
+    for (int r = 0; r < 8; r++) v[r] = cmul(v[r], w.tw[r * 64 + lane]);
     xchg_hi_s(v, w.tile, lane);
     dft8<+1>(v);
 #pragma unroll
@@ -94,10 +94,10 @@ __device__ __forceinline__ void fft_inv_s(cplx (&v)[8], const Br3Ctx &w)
     dft8<-1>(v);
     xchg_hi_s(v, w.tile, lane);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], w.tw[(7 + r) * 64 + lane]);
+    for (int r = 0; r < 8; r++) v[r] = cmulc(v[r], w.tw[r * 64 + lane]);
     dft8<-1>(v);
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = cmulc(v[m], w.tw[m * 64 + lane]);
+    for (int m = 1; m < 8; m++) v[m] = cmulc(v[m], c16(m));
 }
 // three polynomials together (software pipeline over the polynomials as fft_fwd_n)
 __device__ __forceinline__ void fft_fwd3_s(cplx (&v)[KP][8], const Br3Ctx &w)
@@ -106,23 +106,15 @@ __device__ __forceinline__ void fft_fwd3_s(cplx (&v)[KP][8], const Br3Ctx &w)
     {
         cplx t[8];
 #pragma unroll
-        for (int m = 0; m < 8; m++) t[m] = w.tw[m * 64 + lane];
-        issue_fence();
-#pragma unroll
-        for (int p = 0; p < KP; p++)
-#pragma unroll
-            for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], t[m]);
-    }
-    {
-        cplx t[7];
-#pragma unroll
-        for (int r = 1; r < 8; r++) t[r - 1] = w.tw[(7 + r) * 64 + lane];
+        for (int r = 0; r < 8; r++) t[r] = w.tw[r * 64 + lane];
         issue_fence();
 #pragma unroll
         for (int p = 0; p < KP; p++) {
+#pragma unroll
+            for (int m = 1; m < 8; m++) v[p][m] = cmul(v[p][m], c16(m));
             dft8<+1>(v[p]);
 #pragma unroll
-            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], t[r - 1]);
+            for (int r = 0; r < 8; r++) v[p][r] = cmul(v[p][r], t[r]);
             xchg_hi_s(v[p], w.tile, lane);
         }
     }
@@ -167,9 +159,9 @@ void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
-    // tw_g is the [22][64] table of tx_api.hip: rows 0..14 as they are, rows 15..21 (pass B) depend on lane & 7 only
-    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
-    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    // tw_g is the [15][64] table of tx_api.hip: rows 0..7 as they are, rows 8..14 (pass B) depend on lane & 7 only
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * WAVES + wave;
@@ -314,8 +306,8 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
-    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
-    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int unit = blockIdx.x * WAVES + wave;
@@ -385,8 +377,8 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
     uint32_t *prog = reinterpret_cast<uint32_t *>(lds + BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WAVE_BYTES);
-    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
-    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int first = wave * (int)gridDim.x + (int)blockIdx.x, stride = (int)gridDim.x * BR5_WAVES;
     // a wave without a unit is "finished" from the start: its partner is never behind it
@@ -465,8 +457,8 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
-    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) tw[i] = tw_g[i];
-    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(15 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     int unit = blockIdx.x * WAVES + wave;

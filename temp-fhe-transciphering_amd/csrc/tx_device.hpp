@@ -26,7 +26,7 @@ constexpr int H = 512;            // complex points
 constexpr int KP = 3;             // k + 1 polynomials per GLWE (aes_instances.rs:80)
 constexpr int GL = KP * N;        // words per GLWE
 constexpr int BIG = 2 * N + 1;    // words per big LWE
-constexpr int TW_ROWS = 22;       // 8 twist + 7 pass-A + 7 pass-B rows of 64 complex
+constexpr int TW_ROWS = 15;       // 8 pass-A rows (lane part of the twist folded in) + 7 pass-B rows of 64 complex
 constexpr int XPITCH = 65;        // padded pitch (complex) of the per-wave transpose tile
 constexpr int SCRATCH_CPLX = 8 * XPITCH;   // 8320 bytes per wave
 
@@ -46,6 +46,19 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x +
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 
 #define TXD_SQRT_HALF 0.70710678118654752440
+
+// register part of the twist: exp(i pi m / 16), m = 0..7 (oracle C16[]); m is a compile-time constant at
+// every call site (fully unrolled loops), so the values become literals
+#include "tx_fft_consts.inc"
+__device__ __forceinline__ cplx c16(int m)
+{
+    switch (m) {
+#define TXD_C16_CASE(M, RE, IM) case M: return make_double2(RE, IM);
+        TXD_C16_TABLE(TXD_C16_CASE)
+#undef TXD_C16_CASE
+    }
+    return make_double2(1.0, 0.0);
+}
 
 // 8-point DFT in registers, kernel exp(S 2 pi i n k / 8).  Same operand pairing as oracle dft8().
 template <int S>
@@ -162,18 +175,20 @@ __device__ __forceinline__ void xchg_lo(cplx (&v)[8], cplx *tile, int lane)
     issue_fence();
 }
 
-// forward transform of the 8 complex points held by this lane; tw = [22][64] table in LDS.
+// forward transform of the 8 complex points held by this lane; tw = [15][64] table in LDS.  The twist
+// exp(i pi (64 m + lane)/1024) is applied as constant c16(m) before the first butterfly and as the lane part
+// folded into the pass-A twiddles (rows 0..7) after it.
 __device__ __forceinline__ void fft_fwd(cplx (&v)[8], const cplx *tw, cplx *tile, int lane)
 {
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = cmul(v[m], tw[m * 64 + lane]);
+    for (int m = 1; m < 8; m++) v[m] = cmul(v[m], c16(m));
     dft8<+1>(v);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[(7 + r) * 64 + lane]);
+    for (int r = 0; r < 8; r++) v[r] = cmul(v[r], tw[r * 64 + lane]);
     xchg_hi(v, tile, lane);
     dft8<+1>(v);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[(14 + r) * 64 + lane]);
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[(7 + r) * 64 + lane]);
     xchg_lo(v, tile, lane);
     dft8<+1>(v);
 }
@@ -183,14 +198,14 @@ __device__ __forceinline__ void fft_inv(cplx (&v)[8], const cplx *tw, cplx *tile
     dft8<-1>(v);
     xchg_lo(v, tile, lane);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], tw[(14 + r) * 64 + lane]);
+    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], tw[(7 + r) * 64 + lane]);
     dft8<-1>(v);
     xchg_hi(v, tile, lane);
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], tw[(7 + r) * 64 + lane]);
+    for (int r = 0; r < 8; r++) v[r] = cmulc(v[r], tw[r * 64 + lane]);
     dft8<-1>(v);
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = cmulc(v[m], tw[m * 64 + lane]);
+    for (int m = 1; m < 8; m++) v[m] = cmulc(v[m], c16(m));
 }
 
 
@@ -221,24 +236,18 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
     {
         cplx w[8];
 #pragma unroll
-        for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
+        for (int r = 0; r < 8; r++) w[r] = tw[r * 64 + lane];
         issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
-            for (int m = 0; m < 8; m++) v[p][m] = cmul(v[p][m], w[m]);
-    }
-    fft_stamp(st, 0);
-    {
-        cplx w[7];
-#pragma unroll
-        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
-        issue_fence();
+            for (int m = 1; m < 8; m++) v[p][m] = cmul(v[p][m], c16(m));
+        fft_stamp(st, 0);
 #pragma unroll
         for (int p = 0; p < P; p++) {
             dft8<+1>(v[p]);
 #pragma unroll
-            for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], w[r - 1]);
+            for (int r = 0; r < 8; r++) v[p][r] = cmul(v[p][r], w[r]);
             xchg_hi(v[p], tile, lane);
         }
     }
@@ -246,7 +255,7 @@ __device__ __forceinline__ void fft_fwd_n(cplx (&v)[P][8], const cplx *tw, cplx 
     {
         cplx w[7];
 #pragma unroll
-        for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -272,7 +281,7 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
     {
         cplx w[7];
 #pragma unroll
-        for (int r = 1; r < 8; r++) w[r - 1] = tw[(14 + r) * 64 + lane];
+        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
         issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -283,26 +292,18 @@ __device__ __forceinline__ void fft_inv_n(cplx (&v)[P][8], const cplx *tw, cplx 
         }
     }
     {
-        cplx w[7];
+        cplx w[8];
 #pragma unroll
-        for (int r = 1; r < 8; r++) w[r - 1] = tw[(7 + r) * 64 + lane];
+        for (int r = 0; r < 8; r++) w[r] = tw[r * 64 + lane];
         issue_fence();
 #pragma unroll
         for (int p = 0; p < P; p++) {
 #pragma unroll
-            for (int r = 1; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r - 1]);
+            for (int r = 0; r < 8; r++) v[p][r] = cmulc(v[p][r], w[r]);
             dft8<-1>(v[p]);
+#pragma unroll
+            for (int m = 1; m < 8; m++) v[p][m] = cmulc(v[p][m], c16(m));
         }
-    }
-    {
-        cplx w[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) w[m] = tw[m * 64 + lane];
-        issue_fence();
-#pragma unroll
-        for (int p = 0; p < P; p++)
-#pragma unroll
-            for (int m = 0; m < 8; m++) v[p][m] = cmulc(v[p][m], w[m]);
     }
 }
 

@@ -213,6 +213,6 @@ class Engine:
         return {n: getattr(t, n) for n, _ in TxTiming._fields_}
 
     def twiddles(self):
-        out = np.zeros(22 * 64 * 2, np.float64)
+        out = np.zeros(15 * 64 * 2, np.float64)
         self._chk(lib().tx_get_twiddles(self.h, _pf(out)))
         return out

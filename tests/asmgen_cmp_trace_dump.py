@@ -5,7 +5,7 @@ HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen")); sys.path.insert(0, HERE)
 import gcn, trgen, oracle_lib as O
 N, H, KP = 1024, 512, 3
-TW_BYTES = (15 * 64 + 7 * 8) * 16; WAVE_LDS = 32768
+TW_BYTES = (8 * 64 + 7 * 8) * 16; WAVE_LDS = 32768
 d = os.path.join(ROOT, "gpurun_out", "dbg_trace")
 acc, auto, got = np.load(d + "/acc.npy"), np.load(d + "/auto.npy"), np.load(d + "/out_v4.npy")
 steps = int(os.environ.get("TR_STEPS", 10))
@@ -16,7 +16,7 @@ auto_f = np.zeros((2, std.shape[0], H), np.complex128)
 for i in range(std.shape[0]):
     for s, part in ((0, std[i] & np.uint64((1 << 41) - 1)), (1, std[i] >> np.uint64(41))):
         o = np.zeros(N, np.float64); L.txo_fft_forward_torus_scaled(N, O.p_u64(np.ascontiguousarray(part)), O.p_f64(o)); auto_f[s, i] = o.view(np.complex128)
-tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(22, 64, 2)).copy().view(np.complex128).reshape(22, 64)
+tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(15, 64, 2)).copy().view(np.complex128).reshape(15, 64)
 def prep(a, lvl):
     g = np.zeros((3, N), np.uint64)
     for q in range(2):
@@ -27,8 +27,8 @@ def prep(a, lvl):
     g[2, 0] = (a[2, lvl] + (np.uint64(1) << np.uint64(63 - 2 * (lvl + 1)))) >> np.uint64(10)
     return g
 lds = np.zeros(TW_BYTES + 4 * WAVE_LDS, np.uint8)
-lw = lds.view(np.complex128); lw[:15 * 64] = tw[:15].reshape(-1)
-for r in range(7): lw[15 * 64 + r * 8: 15 * 64 + r * 8 + 8] = tw[15 + r, :8]
+lw = lds.view(np.complex128); lw[:8 * 64] = tw[:8].reshape(-1)
+for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
 with np.errstate(over="ignore"):
     for w in range(4): lds[TW_BYTES + w * WAVE_LDS + 8192: TW_BYTES + w * WAVE_LDS + 8192 + 24576].view(np.uint64)[:] = prep(acc[0], w).reshape(-1)
 AUTO = 0x5000_0000; key_buf = auto_f.reshape(-1).view(np.uint8).copy(); TS = trgen.TS

@@ -18,7 +18,7 @@ import gcn
 import brgen
 
 N, H, KP = 1024, 512, 3
-TW_BYTES = (15 * 64 + 7 * 8) * 16
+TW_BYTES = (8 * 64 + 7 * 8) * 16
 TILE = TW_BYTES                      # wave 0's tile
 LDS_BYTES = TW_BYTES + 16384 + 64      # + the two step counters of the fair variant
 
@@ -96,7 +96,7 @@ def main():
     rng = np.random.default_rng(seed)
     L = oracle()
     H_ = gcn._helpers()
-    tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(22, 64, 2)).copy().view(np.complex128).reshape(22, 64)
+    tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(15, 64, 2)).copy().view(np.complex128).reshape(15, 64)
     # realistic key: transform of uniformly random torus polynomials, scaled by 2/N as the library stores it
     key = np.zeros((steps, KP, KP, H), np.complex128)
     L.txo_fft_forward_torus_scaled.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
@@ -114,8 +114,8 @@ def main():
     # ---- the emulated wave
     lds = np.zeros(LDS_BYTES, np.uint8)
     lw = lds.view(np.complex128)
-    lw[:15 * 64] = tw[:15].reshape(-1)
-    for r in range(7): lw[15 * 64 + r * 8: 15 * 64 + r * 8 + 8] = tw[15 + r, :8]
+    lw[:8 * 64] = tw[:8].reshape(-1)
+    for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
     body = lds[TILE + 8192: TILE + 16384].view(np.uint64)
     rot0 = 2 * N - int(L.txo_modswitch(C.c_uint64(int(lwe[-1])), 10, 3))
     tv = np.zeros(N, np.uint64)

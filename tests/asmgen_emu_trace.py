@@ -19,7 +19,7 @@ import trgen
 import oracle_lib as O
 
 N, H, KP = 1024, 512, 3
-TW_BYTES = (15 * 64 + 7 * 8) * 16
+TW_BYTES = (8 * 64 + 7 * 8) * 16
 WAVE_LDS = 32768
 LDS_BYTES = TW_BYTES + 4 * WAVE_LDS
 
@@ -43,12 +43,12 @@ def main():
             out = np.zeros(N, np.float64)
             L.txo_fft_forward_torus_scaled(N, O.p_u64(np.ascontiguousarray(part)), O.p_f64(out))
             auto_f[s, i] = out.view(np.complex128)
-    tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(22, 64, 2)).copy().view(np.complex128).reshape(22, 64)
+    tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(15, 64, 2)).copy().view(np.complex128).reshape(15, 64)
 
     lds = np.zeros(LDS_BYTES, np.uint8)
     lw = lds.view(np.complex128)
-    lw[:15 * 64] = tw[:15].reshape(-1)
-    for r in range(7): lw[15 * 64 + r * 8: 15 * 64 + r * 8 + 8] = tw[15 + r, :8]
+    lw[:8 * 64] = tw[:8].reshape(-1)
+    for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
     for w in range(4):
         base = TW_BYTES + w * WAVE_LDS + 8192
         lds[base: base + 3 * 8192].view(np.uint64)[:] = glwe[w].reshape(-1)

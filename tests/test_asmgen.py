@@ -39,9 +39,23 @@ def test_generated_trace_loop_equals_oracle_four_waves(oracle):
 def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])
-    for f in ("tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_fair.inc", "tx_br_asm_fair_stamps.inc", "tx_br_asm_clobbers.inc",
+    subprocess.check_call([sys.executable, os.path.join(GEN, "fftconst.py"), "--out", str(tmp_path)])
+    for f in ("tx_fft_consts.inc", "tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_fair.inc", "tx_br_asm_fair_stamps.inc", "tx_br_asm_clobbers.inc",
               "tx_trace_asm.inc", "tx_trace_asm_stamps.inc", "tx_trace_asm_clobbers.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
+
+
+def test_twist_constants_are_the_oracles(oracle):
+    """the literals the HIP templates and the generated assembly carry (tools/asmgen/fftconst.py, correctly rounded
+    from nested radicals) are the oracle's C16[] (long-double cos / sin rounded once) bit for bit"""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, GEN)
+    import fftconst
+    L = oracle.lib()
+    L.txo_twist_consts_1024.restype = C.POINTER(C.c_double)
+    got = np.ctypeslib.as_array(L.txo_twist_consts_1024(), shape=(8, 2))
+    assert np.array_equal(got.view(np.uint64), np.array(fftconst.C16, np.float64).view(np.uint64))
 
 
 def test_register_budget_and_no_scratch():

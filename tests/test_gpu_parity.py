@@ -65,7 +65,7 @@ def rig768():
 def test_twiddle_tables_identical(rig256):
     import ctypes as C
     O = rig256.O
-    t = np.ctypeslib.as_array(O.lib().txo_twiddles_1024(), shape=(22 * 64 * 2,))
+    t = np.ctypeslib.as_array(O.lib().txo_twiddles_1024(), shape=(15 * 64 * 2,))
     assert np.array_equal(rig256.eng.twiddles(), t)
 
 

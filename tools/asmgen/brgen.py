@@ -25,9 +25,10 @@ import os
 import struct
 import sys
 from gcn import V, S, Lit, VCC, Prog
+from fftconst import C16
 
 N, LOGN, H, KP = 1024, 10, 512, 3
-TWB = 15 * 64 * 16                      # byte offset of the compact pass-B twiddles
+TWB = 8 * 64 * 16                       # byte offset of the compact pass-B twiddles (after the eight pass-A rows)
 
 # ---- register map
 LANE, L8T, L16T, L16, OFF1, TWBA, XHW, XLW, EREG, L8, R10, R11 = [V(i) for i in range(12)]
@@ -46,6 +47,7 @@ class SG:
     NSTEP = S(40); I = S(41); TILE = S(42); ROT = S(43); CTV = S(44, 2); TMP = S(46); TMP2 = S(47)
     C_2M64 = S(48, 2); C_M2P64 = S(50, 2); C_84 = S(52, 2); C_52 = S(54, 2); C_SQH = S(56, 2); C_M4338 = S(58)
     KP0 = S(60, 2); KP1 = S(62, 2); KP2 = S(64, 2); KPN = S(66, 2)
+    CS = S(44, 2); CC = S(46, 2)       # twist constants (sin, cos), set where they are used: they share CTV / TMP:TMP2, which are dead inside a transform
     FAIR = S(68); PROGA = S(69); PROGB = S(59); PBASE = S(67)   # fair mode: flag, LDS addresses of my / the partner's step counter, steps done before this unit
 
 
@@ -74,6 +76,8 @@ ST_PREV, ST_NOW, ST_DBG = S(82, 2), S(84, 2), S(86, 2)
 
 
 class Gen:
+    CC, CS = SG.CC, SG.CS
+
     def __init__(self, stamps=False, prio="I", deep_prefetch=True, phase_stamps=True, fair=False):
         self.stamps = stamps
         # fair: the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup) exchange their step counters
@@ -256,14 +260,20 @@ class Gen:
         return Cx.of(x.q), Cx.of(spare), y.q
 
     def cmul(self, q, w, tmp):         # q *= w        cmul(): t = y*wy; u = y*wx; re = fma(x, wx, -t); im = fma(x, wy, u)
-        x, y, wx, wy = qre(q), qim(q), qre(w), qim(w)
+        self.cmul_w(q, qre(w), qim(w), tmp)
+
+    def cmulc(self, q, w, tmp, tmp2):  # q *= conj(w)  cmulc(): t = y*wy; u = x*wy; re = fma(x, wx, t); im = fma(y, wx, -u)
+        self.cmulc_w(q, qre(w), qim(w), tmp, tmp2)
+
+    def cmul_w(self, q, wx, wy, tmp):  # the factor's components are any 64-bit operands (register pairs or scalar constants)
+        x, y = qre(q), qim(q)
         self.e("v_mul_f64", tmp, y, wy)
         self.e("v_mul_f64", y, y, wx)
         self.e("v_fma_f64", y, x, wy, y)
         self.e("v_fma_f64", x, x, wx, -tmp)
 
-    def cmulc(self, q, w, tmp, tmp2):  # q *= conj(w)  cmulc(): t = y*wy; u = x*wy; re = fma(x, wx, t); im = fma(y, wx, -u)
-        x, y, wx, wy = qre(q), qim(q), qre(w), qim(w)
+    def cmulc_w(self, q, wx, wy, tmp, tmp2):
+        x, y = qre(q), qim(q)
         self.e("v_mul_f64", tmp, y, wy)
         self.e("v_mul_f64", tmp2, x, wy)
         self.e("v_fma_f64", y, y, wx, -tmp2)
@@ -279,6 +289,30 @@ class Gen:
             chains = [self.chain(fn, pairs[k][0], pairs[k][1], *tA)]
             if k + 1 < len(pairs): chains.append(self.chain(fn, pairs[k + 1][0], pairs[k + 1][1], *tB))
             self.merge(chains)
+
+    def twist_consts(self, polys, spare, conj):
+        """register part of the twist (c16() of tx_device.hpp): v[m] *= exp(+-i pi m/16), m = 1..7, for each list of 8
+        quads in polys.  exp(i pi m/16) = (c, s) and exp(i pi (8-m)/16) = (s, c): one pair of scalar constants serves two
+        registers; m = 4 is (sqrt 1/2, sqrt 1/2), which the butterflies keep anyway.  Two chains in flight."""
+        e = self.e
+        for mm in (1, 2, 3, 4):
+            if mm < 4:
+                for sreg, val in ((self.CC, C16[mm][0]), (self.CS, C16[mm][1])):
+                    b = f64bits(val)
+                    e("s_mov_b32", sreg.lo(), Lit(b & 0xFFFFFFFF)); e("s_mov_b32", sreg.hi(), Lit(b >> 32))
+                jobs = []
+                for v in polys: jobs += [(v[mm], self.CC, self.CS), (v[8 - mm], self.CS, self.CC)]
+            else:
+                assert C16[4][0] == C16[4][1] == 0.70710678118654752440
+                jobs = [(v[4], SG.C_SQH, SG.C_SQH) for v in polys]
+            for k in range(0, len(jobs), 2):
+                if conj:
+                    chains = [self.chain(self.cmulc_w, *jobs[k], T0, T1)]
+                    if k + 1 < len(jobs): chains.append(self.chain(self.cmulc_w, *jobs[k + 1], qre(spare), qim(spare)))
+                else:
+                    chains = [self.chain(self.cmul_w, *jobs[k], T0)]
+                    if k + 1 < len(jobs): chains.append(self.chain(self.cmul_w, *jobs[k + 1], T1))
+                self.merge(chains)
 
     def dft8(self, v, spare, sign):
         """8-point DFT of the complex values in quads v[0..7] (dft8<sign> of tx_device.hpp, same pairing).
@@ -377,15 +411,13 @@ class Gen:
         On return polys[p][r] is the quad holding F-layout register r of polynomial p."""
         tw, spare = xq[:8], xq[8]
         home_lo = [min(q.i for q in polys[p]) for p in range(3)]
-        self.c("forward x3: twist")
-        self.load_tw(tw, 0, 8)
-        for p in range(3):
-            self.cmul_all([(polys[p][m], tw[m]) for m in range(8)])
-        self.c("forward x3: pass 1 (dft8, pass-A twiddles, exchange hi)")
-        self.load_tw(tw, 8, 7)
+        self.c("forward x3: twist constants")
+        self.load_tw(tw, 0, 8)                                 # in flight during the constant multiplications
+        self.twist_consts(polys, None, conj=False)
+        self.c("forward x3: pass 1 (dft8, pass-A twiddles with the lane part of the twist, exchange hi)")
         for p in range(3):
             polys[p], spare = self.dft8(polys[p], spare, +1)
-            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)])
+            self.cmul_all([(polys[p][r], tw[r]) for r in range(8)])
             self.xchg_hi_write(polys[p])
             # the stores captured their data: the eight quads + the spare are free; read back into a canonical set
             free = sorted(polys[p] + [spare], key=lambda q: q.i)
@@ -422,20 +454,19 @@ class Gen:
         self.lg_wait(set().union(*[self.regs(q) for q in v]))
         self.c("inverse: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
         self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
-        self.load_tw(tw, 8, 7)
+        self.load_tw(tw, 0, 8)
         v, spare = self.dft8(v, spare, -1)
         self.xchg_hi_write(v)
         free = sorted(v + [spare], key=lambda q: q.i)
         v, spare = free[:8], free[8]
         self.xchg_read(v, swz=False)
         self.lg_wait(set().union(*[self.regs(q) for q in v]))
-        self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist)")
-        self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
-        self.load_tw(tw, 0, 8)
+        self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
+        self.cmul_all([(v[r], tw[r]) for r in range(8)], spare, conj=True)
         home_lo = min(q.i for q in v)
         v, spare = self.dft8(v, spare, -1)
         v, spare = self.home(v, spare, home_lo, home_lo + 32)
-        self.cmul_all([(v[m], tw[m]) for m in range(8)], spare, conj=True)
+        self.twist_consts([v], spare, conj=True)
         return v, spare
 
     def inv3(self, polys, xq):
@@ -454,20 +485,18 @@ class Gen:
         self.c("inverse x3: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
         for p in range(3):
             self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
-            if p == 2: self.load_tw(tw, 8, 7)                # the pass-A rows replace the pass-B rows after their last use
+            if p == 2: self.load_tw(tw, 0, 8)                # the pass-A rows replace the pass-B rows after their last use
             polys[p], spare = self.dft8(polys[p], spare, -1)
             self.xchg_hi_write(polys[p])
             free = sorted(polys[p] + [spare], key=lambda q: q.i)
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=False)
-        self.c("inverse x3: pass 1' (pass-A twiddles conj, dft8, untwist)")
+        self.c("inverse x3: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
         for p in range(3):
-            self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
-            if p == 2: self.load_tw(tw, 0, 8)
+            self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spare, conj=True)
             polys[p], spare = self.dft8(polys[p], spare, -1)
             polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
-        for p in range(3):
-            self.cmul_all([(polys[p][m], tw[m]) for m in range(8)], spare, conj=True)
+        self.twist_consts(polys, spare, conj=True)
         return polys, spare
 
     # ---------------------------------------------------------------- integer <-> double

@@ -12,7 +12,7 @@ the GLWE in LDS.  Arithmetic, operation order and results are those of trace_lds
 
     python3 tools/asmgen/trgen.py --out temp-fhe-transciphering_amd/csrc      (tx_trace_asm.inc + clobbers)
 
-LDS image (k_extract_trace4 / k_trace4 in tx_br2.hpp): compact twiddles at 0 (16 256 B), then per wave 32 KiB:
+LDS image (k_extract_trace4 / k_trace4 in tx_br2.hpp): compact twiddles at 0 (9 088 B), then per wave 32 KiB:
 8 KiB unpadded transpose tile (= ring slot of that wave) + the GLWE, 3 x 1024 torus words in natural order.
 
 Register map (VGPR): 0..15 as brgen.py (4: DMA source offset, 8: top-level tie mask, 9: gather index of m = 0),
@@ -48,6 +48,8 @@ class TS:      # scalar registers of this loop (constants at 48..58 and carries 
 
 
 class TraceGen(Gen):
+    CC, CS = TS.KP_, S(44, 2)         # twist constants: the DMA pointer and C64:T are dead inside a transform
+
     def __init__(self, steps=LOGN, stop_after=None, stamps=False):
         super().__init__(stamps=stamps, prio="")
         self.steps = steps                # debugging: fewer trace steps
