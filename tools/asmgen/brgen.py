@@ -227,10 +227,16 @@ class Gen:
             e("v_mov_b32", T1.lo(), ST_NOW.lo()); e("v_mov_b32", T1.hi(), ST_NOW.hi())
             e("global_store_dwordx2", T0.hi(), T1, ST_DBG, offset=8 * (slot + k))
 
-    def stamp(self, k):
+    SUB = os.environ.get("GEN_SUBSTAMPS", "")     # "inv3" / "fwd3" / "inv1": the stamps go inside that transform (accumulators 0..3), everything else to 5
+
+    def substamp(self, where, k):
+        if self.SUB == where: self.stamp(k, raw=True)
+
+    def stamp(self, k, raw=False):
         """diagnostic build only: cycles since the previous stamp are added to accumulator k (s_memtime returns
         through lgkmcnt, so the LDS queue is drained first: the stamps perturb what they measure)"""
         if not self.stamps or not self.phase_stamps: return
+        if self.SUB and not raw and k is not None: k = 5
         self.lg_wait_all()
         self.e("s_memtime", ST_NOW)
         self.lg_wait_all()
@@ -412,8 +418,10 @@ class Gen:
         tw, spare = xq[:8], xq[8]
         home_lo = [min(q.i for q in polys[p]) for p in range(3)]
         self.c("forward x3: twist constants")
+        self.substamp("fwd3", 5)
         self.load_tw(tw, 0, 8)                                 # in flight during the constant multiplications
         self.twist_consts(polys, None, conj=False)
+        self.substamp("fwd3", 0)
         self.c("forward x3: pass 1 (dft8, pass-A twiddles with the lane part of the twist, exchange hi)")
         for p in range(3):
             polys[p], spare = self.dft8(polys[p], spare, +1)
@@ -424,6 +432,7 @@ class Gen:
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=False)
         self.c("forward x3: pass 2 (dft8, pass-B twiddles, exchange lo)")
+        self.substamp("fwd3", 1)
         self.load_tw(tw, 0, 7, compact=True)
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
@@ -434,11 +443,13 @@ class Gen:
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=True)
         self.c("forward x3: pass 3 (dft8)")
+        self.substamp("fwd3", 2)
         if before_pass3: before_pass3()            # the twiddle quads xq[0..7] are free from here on
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
             polys[p], spare = self.dft8(polys[p], spare, +1)
             polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
+        self.substamp("fwd3", 3)
         return polys, spare
 
     def inv1(self, v, xq):
@@ -475,6 +486,7 @@ class Gen:
         tw, spare = xq[:8], xq[8]
         home_lo = [min(q.i for q in polys[p]) for p in range(3)]
         self.c("inverse x3: pass 3' (dft8, exchange lo)")
+        self.substamp("inv3", 5)
         self.load_tw(tw, 0, 7, compact=True)
         for p in range(3):
             polys[p], spare = self.dft8(polys[p], spare, -1)
@@ -483,6 +495,7 @@ class Gen:
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=True)
         self.c("inverse x3: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
+        self.substamp("inv3", 0)
         for p in range(3):
             self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
             if p == 2: self.load_tw(tw, 0, 8)                # the pass-A rows replace the pass-B rows after their last use
@@ -492,11 +505,14 @@ class Gen:
             polys[p], spare = free[:8], free[8]
             self.xchg_read(polys[p], swz=False)
         self.c("inverse x3: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
+        self.substamp("inv3", 1)
         for p in range(3):
             self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spare, conj=True)
             polys[p], spare = self.dft8(polys[p], spare, -1)
             polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
+        self.substamp("inv3", 2)
         self.twist_consts(polys, spare, conj=True)
+        self.substamp("inv3", 3)
         return polys, spare
 
     # ---------------------------------------------------------------- integer <-> double

@@ -293,6 +293,7 @@ class Emu:
     def op_s_mul_i32(self, d, a, b): self.s[d.i] = (self.sval(a) * self.sval(b)) & 0xFFFFFFFF
     def op_s_nop(self, n): pass
     def op_s_setprio(self, n): pass
+    def op_s_sleep(self, n): pass
 
     def op_s_waitcnt(self, vm=None, lgkm=None):
         if vm is not None: self.retire(self.vmq, vm)

@@ -38,6 +38,7 @@ K = [160, 192]
 GA = [V(224 + m) for m in range(16)]
 GS = [V(240 + m) for m in range(16)]
 WAVE_LDS = 32768
+ABL = os.environ.get("TR_ABL", "")        # timing-only ablations of the key pass (D no DMA, B no barriers, R no slot reads, A no AGPR reads, M no MAC): outputs invalid
 GL = 8192                                  # the GLWE follows the tile
 
 
@@ -61,6 +62,7 @@ class TraceGen(Gen):
         q, i, c = j // 9, (j // 3) % 3, j % 3
         off = ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
         e = self.e
+        if "D" in ABL: return
         e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
         e("s_addc_u32", TS.KP_.hi(), TS.PB.hi(), Lit(0))
         # destination: slot0 + (j % 4) * 32 KiB + wave * 2 KiB (wave-uniform, in M0)
@@ -73,12 +75,30 @@ class TraceGen(Gen):
         e("global_load_lds_dwordx4", DMAOFF2, TS.KP_, offset=0)      # no instruction offset on an LDS-DMA load: it would also move the LDS address
         self.vmq.append({1000 + j})
 
+    SKEW = int(os.environ.get("TR_SKEW", 4))     # s_sleep units (64 cycles) of phase offset per wave index
+
+    def skew(self):
+        """Wave w waits w * SKEW * 64 cycles.  The four waves of a workgroup leave a barrier together and run the same
+        code: without an offset all four reach every tile exchange at the same moment and queue on the CU's LDS store
+        path (a ds_write_b128 holds it for 13 cycles, 26 when only one SIMD of a half is storing), each blocked behind
+        the others' stores instead of running its butterflies."""
+        if not self.SKEW: return
+        e = self.e
+        self.nlab += 1
+        lab = "L_sk%d_%%=" % self.nlab
+        for w in range(1, 4):
+            e("s_cmp_lt_u32", TS.WAVE, Lit(w))
+            e("s_cbranch_scc1", lab)
+            e("s_sleep", Lit(self.SKEW))
+        self.p.label(lab)
+
     def ring_barrier(self, need=None):
         """this wave's LDS traffic done and (need: key polynomial) its DMA landed, then the workgroup barrier"""
         if need is not None:
             k = self._wait(self.vmq, {1000 + need}, 63)
             if k is not None: self.p.emit("s_waitcnt", vm=k)
         self.lg_wait_all()
+        if "B" in ABL and need is not None: return
         self.p.emit("s_barrier")
 
     # ------------------------------------------------------------------ decomposition (Decomp<13, 3>, finest level first)
@@ -239,11 +259,13 @@ class TraceGen(Gen):
             for j in range(3): self.dma(j)
 
             def load_dc(g):
+                if "A" in ABL: return
                 for r in range(8):
                     for k in range(4):
                         self.e("v_accvgpr_read_b32", V(DCq[r].i + k), A((g * 8 + r) * 4 + k))
 
             def mac(j, r):
+                if "M" in ABL: return
                 c, g, d, first = j % KP, KS[j % 2][r], DCq[r], j < KP
                 re0 = Lit(0, f64=0.0) if first else qre(Fq[c][r])
                 im0 = Lit(0, f64=0.0) if first else qim(Fq[c][r])
@@ -257,11 +279,13 @@ class TraceGen(Gen):
                 for r in range(0, 8, 2): self.merge([self.chain(mac, j, r), self.chain(mac, j, r + 1)])
             for j in range(NK):
                 self.ring_barrier(need=j)                        # polynomial j landed everywhere; slot (j - 1) % 4 is free
-                for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SL[j % 4], offset=1024 * r)
+                if "R" not in ABL:
+                    for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SL[j % 4], offset=1024 * r)
                 if j + 3 < NK: self.dma(j + 3)
                 if j >= 1: macs(j - 1)                           # covers the slot read above
             macs(NK - 1)
             self.ring_barrier()                                  # every wave has read the last slot: tiles free again
+            self.skew()
             self.stamp(2)
             # ---- three inverse transforms together, then the accumulation into the GLWE
             xq = [quad(K[0], r) for r in range(8)] + [quad(K[1], r) for r in range(8)] + [quad(DC, r) for r in range(8)]
@@ -311,6 +335,7 @@ class TraceGen(Gen):
 
     def build(self):
         self.prologue()
+        self.skew()
         self.step()
         self.lg_wait_all()
         if self.stamps:

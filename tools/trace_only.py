@@ -23,4 +23,5 @@ if hasattr(txhip.lib(), "tx_debug_stamps"):
     txhip.lib().tx_debug_stamps(C.c_void_p(eng.h), st)
     names = ["gather+decompose+forward x6", "body", "key pass (MAC)", "inverse x3", "convert+update"]
     steps = max(1, st[6])
+    print("raw stamps / step:", [round(st[i] / steps) for i in range(6)])
     print("stamps (cycles/trace step):", {n: round(st[i] / steps) for i, n in enumerate(names)}, "sum", round(sum(st[:5]) / steps))
