@@ -23,51 +23,29 @@
 
 namespace txd {
 
-// ---- LDS image of this kernel: 2 workgroups of 256 threads per CU, 80 KiB each ----
+// ---- LDS image of the generated kernels ----
 //   pass-A 8 rows of 64 complex (as tx_device.hpp), pass-B 7 rows of EIGHT complex (the pass-B twiddle depends on
-//   lane & 7 only): 9 088 B; then per wave an UNPADDED 8 KiB transpose tile and the 8 KiB body.
-//   9 088 + 4 x 16 384 = 74 624 B <= 81 920 B.  The pitch-65 padding of tx_device.hpp (512 B per workgroup) would
-//   not fit, so the second exchange stores column (8g + r) ^ b of row b instead (XOR swizzle): 8 consecutive lanes
-//   of a ds_write_b128 still hit 8 distinct bank quads, and a ds_read_b128 reads lane ^ r', a permutation inside
-//   aligned groups of 8 columns, which keeps its 16-lane groups on 16 distinct quads.  The first exchange needs no
-//   skew at all: its 8-lane store groups are contiguous 128-byte runs.
+//   lane & 7 only): 9 088 B; then per wave the transpose tile of tx_device.hpp (pitch 65 complex, 8 320 B: every
+//   b128 store and load of both exchanges is conflict-free without address arithmetic) and the 8 KiB body (blind
+//   rotation) or the 24 KiB GLWE (trace).  Two 256-thread workgroups per CU: 9 088 + 4 x 16 512 = 75 136 B <= 81 920 B.
+//   (The first versions of this layout carried the 16 256-byte twiddle table and needed an unpadded, XOR-swizzled tile
+//   to fit; the split twist freed the space, and the swizzle's 16 v_xor per exchange went with it.)
 constexpr int BR3_TWB = 8 * 64;                              // first pass-B entry (complex units)
 constexpr int BR3_TW_CPLX = 8 * 64 + 7 * 8;
-constexpr size_t BR3_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)N * sizeof(uint64_t);
+constexpr size_t BR3_TILE_BYTES = (size_t)SCRATCH_CPLX * sizeof(cplx);          // 8 320
+constexpr size_t BR3_WAVE_BYTES = BR3_TILE_BYTES + (size_t)N * sizeof(uint64_t);
 constexpr size_t LDS_BYTES_BR3 = BR3_TW_CPLX * sizeof(cplx) + WAVES * BR3_WAVE_BYTES;
 static_assert(LDS_BYTES_BR3 <= 80 * 1024, "two workgroups per CU");
 
 #ifdef TXD_WITH_BR3   // the hipcc version of this layout: readable specification of the generated loop, not built by default
 struct Br3Ctx {
     const cplx *tw;     // pass-A rows 0..7, pass-B compact at BR3_TWB
-    cplx *tile;         // 512 complex, unpadded
+    cplx *tile;         // transpose tile, pitch XPITCH (also staged as 1024 torus words)
     uint64_t *pl;       // the tile as 1024 torus words
     uint64_t *bl;       // body polynomial
     int lane;
 };
 
-//   xchg_hi: element (lane = 8a+b, reg r)  ->  (lane = 8r+b, reg a)
-__device__ __forceinline__ void xchg_hi_s(cplx (&v)[8], cplx *tile, int lane)
-{
-    const int a = lane >> 3, b = lane & 7;
-#pragma unroll
-    for (int r = 0; r < 8; r++) tile[a * 64 + 8 * r + b] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = tile[r * 64 + lane];
-    issue_fence();
-}
-//   xchg_lo: element (lane = 8g+b, reg r)  ->  (lane = 8g+r, reg b); column XOR-swizzled by the row
-__device__ __forceinline__ void xchg_lo_s(cplx (&v)[8], cplx *tile, int lane)
-{
-    const int g8 = lane & ~7, b = lane & 7;
-#pragma unroll
-    for (int r = 0; r < 8; r++) tile[b * 64 + ((g8 + r) ^ b)] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = tile[r * 64 + (lane ^ r)];
-    issue_fence();
-}
 // same arithmetic per polynomial as fft_fwd / fft_inv (tx_device.hpp); twiddles are read where they are used
 __device__ __forceinline__ void fft_fwd_s(cplx (&v)[8], const Br3Ctx &w)
 {
@@ -77,22 +55,22 @@ __device__ __forceinline__ void fft_fwd_s(cplx (&v)[8], const Br3Ctx &w)
     dft8<+1>(v);
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = cmul(v[r], w.tw[r * 64 + lane]);
-    xchg_hi_s(v, w.tile, lane);
+    xchg_hi(v, w.tile, lane);
     dft8<+1>(v);
 #pragma unroll
     for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w.tw[BR3_TWB + (r - 1) * 8 + (lane & 7)]);
-    xchg_lo_s(v, w.tile, lane);
+    xchg_lo(v, w.tile, lane);
     dft8<+1>(v);
 }
 __device__ __forceinline__ void fft_inv_s(cplx (&v)[8], const Br3Ctx &w)
 {
     const int lane = w.lane;
     dft8<-1>(v);
-    xchg_lo_s(v, w.tile, lane);
+    xchg_lo(v, w.tile, lane);
 #pragma unroll
     for (int r = 1; r < 8; r++) v[r] = cmulc(v[r], w.tw[BR3_TWB + (r - 1) * 8 + (lane & 7)]);
     dft8<-1>(v);
-    xchg_hi_s(v, w.tile, lane);
+    xchg_hi(v, w.tile, lane);
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = cmulc(v[r], w.tw[r * 64 + lane]);
     dft8<-1>(v);
@@ -115,7 +93,7 @@ __device__ __forceinline__ void fft_fwd3_s(cplx (&v)[KP][8], const Br3Ctx &w)
             dft8<+1>(v[p]);
 #pragma unroll
             for (int r = 0; r < 8; r++) v[p][r] = cmul(v[p][r], t[r]);
-            xchg_hi_s(v[p], w.tile, lane);
+            xchg_hi(v[p], w.tile, lane);
         }
     }
     {
@@ -128,7 +106,7 @@ __device__ __forceinline__ void fft_fwd3_s(cplx (&v)[KP][8], const Br3Ctx &w)
             dft8<+1>(v[p]);
 #pragma unroll
             for (int r = 1; r < 8; r++) v[p][r] = cmul(v[p][r], t[r - 1]);
-            xchg_lo_s(v[p], w.tile, lane);
+            xchg_lo(v[p], w.tile, lane);
         }
     }
 #pragma unroll
@@ -170,7 +148,7 @@ void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     w.tw = tw;
     w.tile = reinterpret_cast<cplx *>(lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES);
     w.pl = reinterpret_cast<uint64_t *>(w.tile);
-    w.bl = w.pl + N;
+    w.bl = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(w.tile) + BR3_TILE_BYTES);
     w.lane = lane;
     uint64_t *bl = w.bl;
     const uint32_t thr = 0x400000u - (uint32_t)(lane & 1);
@@ -313,7 +291,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     const int unit = blockIdx.x * WAVES + wave;
     if (unit >= count) return;
     unsigned char *tile = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES;
-    uint64_t *bl = reinterpret_cast<uint64_t *>(tile) + N;
+    uint64_t *bl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
     const uint64_t *ct = lwe + (size_t)unit * (n + 1);
     {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
         const int rot = 2 * N - (int)modswitch(ct[n]);
@@ -385,7 +363,7 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     if ((threadIdx.x & 63) == 0) prog[wave] = (first < count) ? 0u : 0xFFFFFFFFu;
     __syncthreads();
     unsigned char *tile = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)wave * BR3_WAVE_BYTES;
-    uint64_t *bl = reinterpret_cast<uint64_t *>(tile) + N;
+    uint64_t *bl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
     const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
     const uint32_t prog_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)prog);
     const uint32_t prog_a = prog_addr + 4u * (uint32_t)wave, prog_b = prog_addr + 4u * (uint32_t)(wave ^ 4);
@@ -445,11 +423,11 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // (tx_trace_asm.inc): one wave per SIMD as before, but the six digit transforms of a step are parked in accumulation
 // registers, which leaves room for two key register sets (the LDS read of the next key polynomial is in flight
 // while the current one is multiplied) and three-way interleaved transforms in both directions.  LDS image: the
-// compact twiddles of k_blind_rotate3/4, then per wave an unpadded 8 KiB tile (= that wave's ring slot) and the
+// compact twiddles of k_blind_rotate3/4, then per wave the 8 320-byte tile (its first 8 KiB = that wave's ring slot) and the
 // 24 KiB GLWE.  Same ring protocol (KeyRing, tx_kernels.hpp): every wave takes part in every barrier, so idle
 // waves of the last workgroup shadow the last unit.  Bit-identical to k_extract_trace and the oracle.
 // ------------------------------------------------------------------------------------------
-constexpr size_t TR4_WAVE_BYTES = (size_t)H * sizeof(cplx) + (size_t)GL * sizeof(uint64_t);
+constexpr size_t TR4_WAVE_BYTES = BR3_TILE_BYTES + (size_t)GL * sizeof(uint64_t);
 constexpr size_t LDS_BYTES_TR4 = BR3_TW_CPLX * sizeof(cplx) + WAVES * TR4_WAVE_BYTES;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -466,7 +444,7 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
     if (!active) unit = count * CBS_L - 1;          // own LDS): every wave takes part in the key ring's barriers
     unsigned char *slot0 = lds + BR3_TW_CPLX * sizeof(cplx);
     unsigned char *tile = slot0 + (size_t)wave * TR4_WAVE_BYTES;
-    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + H * sizeof(cplx));
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
     const int ctx = unit / CBS_L, lvl = unit % CBS_L;
     const uint64_t *a = acc + (size_t)ctx * GL;
     // buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const  (as k_extract_trace)

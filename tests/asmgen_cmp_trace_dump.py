@@ -5,7 +5,7 @@ HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen")); sys.path.insert(0, HERE)
 import gcn, trgen, oracle_lib as O
 N, H, KP = 1024, 512, 3
-TW_BYTES = (8 * 64 + 7 * 8) * 16; WAVE_LDS = 32768
+TW_BYTES = (8 * 64 + 7 * 8) * 16; WAVE_LDS = 8320 + 3 * 8192
 d = os.path.join(ROOT, "gpurun_out", "dbg_trace")
 acc, auto, got = np.load(d + "/acc.npy"), np.load(d + "/auto.npy"), np.load(d + "/out_v4.npy")
 steps = int(os.environ.get("TR_STEPS", 10))
@@ -30,7 +30,7 @@ lds = np.zeros(TW_BYTES + 4 * WAVE_LDS, np.uint8)
 lw = lds.view(np.complex128); lw[:8 * 64] = tw[:8].reshape(-1)
 for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
 with np.errstate(over="ignore"):
-    for w in range(4): lds[TW_BYTES + w * WAVE_LDS + 8192: TW_BYTES + w * WAVE_LDS + 8192 + 24576].view(np.uint64)[:] = prep(acc[0], w).reshape(-1)
+    for w in range(4): lds[TW_BYTES + w * WAVE_LDS + 8320: TW_BYTES + w * WAVE_LDS + 8320 + 24576].view(np.uint64)[:] = prep(acc[0], w).reshape(-1)
 AUTO = 0x5000_0000; key_buf = auto_f.reshape(-1).view(np.uint8).copy(); TS = trgen.TS
 prog = trgen.TraceGen(steps=steps).build(); emus = []
 for w in range(4):
@@ -38,7 +38,7 @@ for w in range(4):
     e.s[TS.WAVE.i] = w; e.s[TS.SLOT0.i] = TW_BYTES; e.s[TS.TILE.i] = TW_BYTES + w * WAVE_LDS; emus.append(e)
 gcn.run_group(emus, prog)
 for w in range(4):
-    exp = lds[TW_BYTES + w * WAVE_LDS + 8192: TW_BYTES + w * WAVE_LDS + 8192 + 24576].view(np.uint64).reshape(3, N)
+    exp = lds[TW_BYTES + w * WAVE_LDS + 8320: TW_BYTES + w * WAVE_LDS + 8320 + 24576].view(np.uint64).reshape(3, N)
     for q in range(3):
         bad = np.nonzero(exp[q] != got[w, q])[0]
         print("unit", w, "poly", q, "mismatches", bad.size, bad[:10], [hex(int(x)) for x in got[w, q][bad[:2]]], [hex(int(x)) for x in exp[q][bad[:2]]])

@@ -20,7 +20,8 @@ import brgen
 N, H, KP = 1024, 512, 3
 TW_BYTES = (8 * 64 + 7 * 8) * 16
 TILE = TW_BYTES                      # wave 0's tile
-LDS_BYTES = TW_BYTES + 16384 + 64      # + the two step counters of the fair variant
+WAVE_BYTES = 8320 + 8192               # padded tile (pitch 65 complex) + body polynomial
+LDS_BYTES = TW_BYTES + WAVE_BYTES + 64   # + the two step counters of the fair variant
 
 
 def oracle():
@@ -116,7 +117,7 @@ def main():
     lw = lds.view(np.complex128)
     lw[:8 * 64] = tw[:8].reshape(-1)
     for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
-    body = lds[TILE + 8192: TILE + 16384].view(np.uint64)
+    body = lds[TILE + 8320: TILE + WAVE_BYTES].view(np.uint64)
     rot0 = 2 * N - int(L.txo_modswitch(C.c_uint64(int(lwe[-1])), 10, 3))
     tv = np.zeros(N, np.uint64)
     for i in range(N):
@@ -136,8 +137,8 @@ def main():
     fair = os.environ.get('BR_FAIR')            # '0': partner never ahead, '1': partner always ahead (both priority paths)
     prog = brgen.Gen(stamps=bool(os.environ.get('BR_STAMPS')), fair=fair is not None).build()
     if fair is not None:
-        emu.s[SG.PROGA.i] = TW_BYTES + 16384; emu.s[SG.PROGB.i] = TW_BYTES + 16384 + 4; emu.s[SG.PBASE.i] = 1536
-        lds[TW_BYTES + 16384 + 4: TW_BYTES + 16384 + 8].view(np.uint32)[0] = 0xFFFFFFFF if fair == '1' else 0
+        emu.s[SG.PROGA.i] = TW_BYTES + WAVE_BYTES; emu.s[SG.PROGB.i] = TW_BYTES + WAVE_BYTES + 4; emu.s[SG.PBASE.i] = 1536
+        lds[TW_BYTES + WAVE_BYTES + 4: TW_BYTES + WAVE_BYTES + 8].view(np.uint32)[0] = 0xFFFFFFFF if fair == '1' else 0
     if os.environ.get('BR_STAMPS'):
         dbg = np.zeros(128, np.uint8); emu.g.append((0x4000_0000, dbg)); emu.s[brgen.ST_DBG.i] = 0x4000_0000; emu.s[brgen.ST_DBG.i + 1] = 0
     t = time.time()

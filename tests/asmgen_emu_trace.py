@@ -20,7 +20,7 @@ import oracle_lib as O
 
 N, H, KP = 1024, 512, 3
 TW_BYTES = (8 * 64 + 7 * 8) * 16
-WAVE_LDS = 32768
+WAVE_LDS = 8320 + 3 * 8192             # padded tile + GLWE
 LDS_BYTES = TW_BYTES + 4 * WAVE_LDS
 
 
@@ -50,7 +50,7 @@ def main():
     lw[:8 * 64] = tw[:8].reshape(-1)
     for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
     for w in range(4):
-        base = TW_BYTES + w * WAVE_LDS + 8192
+        base = TW_BYTES + w * WAVE_LDS + 8320
         lds[base: base + 3 * 8192].view(np.uint64)[:] = glwe[w].reshape(-1)
     AUTO = 0x5000_0000
     key_buf = auto_f.reshape(-1).view(np.uint8).copy()
@@ -69,7 +69,7 @@ def main():
     gcn.run_group(emus, prog)
     ok = True
     for w in range(4):
-        base = TW_BYTES + w * WAVE_LDS + 8192
+        base = TW_BYTES + w * WAVE_LDS + 8320
         got = lds[base: base + 3 * 8192].view(np.uint64).reshape(KP, N)
         if not np.array_equal(got, ref[w]):
             ok = False

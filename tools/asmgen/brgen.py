@@ -29,6 +29,8 @@ from fftconst import C16
 
 N, LOGN, H, KP = 1024, 10, 512, 3
 TWB = 8 * 64 * 16                       # byte offset of the compact pass-B twiddles (after the eight pass-A rows)
+PITCH = 65 * 16                         # bytes per row of the transpose tile: 64 complex + one of padding (XPITCH of tx_device.hpp)
+BODY = 8 * PITCH                        # the body polynomial (blind rotation) / the GLWE (trace) follows the 8 320-byte tile
 
 # ---- register map
 LANE, L8T, L16T, L16, OFF1, TWBA, XHW, XLW, EREG, L8, R10, R11 = [V(i) for i in range(12)]
@@ -390,19 +392,13 @@ class Gen:
         for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
 
     def xchg_read(self, dst, swz):
+        """row r of the tile, this lane's column (both exchanges read the same way; swz is kept for the call sites)"""
         if "X" in ABL: return
-        for r in range(8):
-            if swz:
-                self.e("v_xor_b32", T1.lo(), Lit(r << 4), L16T)
-                self.ds_read("ds_read_b128", dst[r], T1.lo(), offset=1024 * r)
-            else:
-                self.ds_read("ds_read_b128", dst[r], L16T, offset=1024 * r)
+        for r in range(8): self.ds_read("ds_read_b128", dst[r], L16T, offset=PITCH * r)
 
     def xchg_lo_write(self, v):
         if "X" in ABL: return
-        for r in range(8):
-            self.e("v_xor_b32", T1.lo(), Lit(r << 4), XLW)
-            self.ds_write("ds_write_b128", T1.lo(), v[r], offset=0)
+        for r in range(8): self.ds_write("ds_write_b128", XLW, v[r], offset=16 * r)
 
     def load_tw(self, dst, row0, nrows, compact=False):
         """twiddle rows row0.. into quads dst[0..nrows-1]"""
@@ -562,13 +558,16 @@ class Gen:
         e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
         e("v_add_u32", TWBA, Lit(TWB), TWBA)
         e("v_lshrrev_b32", T0.hi(), Lit(3), LANE)               # a
-        e("v_lshl_add_u32", T0.hi(), T0.hi(), Lit(6), T0.lo())  # a*64 + b
+        # tile rows have a pitch of 65 complex (tx_device.hpp): exchange hi stores element r at row a, column 8 r + b;
+        # exchange lo at row b, column g8 + r; both read row r, column lane -- every b128 access conflict-free, no swizzle
+        assert PITCH == 65 * 16
+        e("v_lshl_add_u32", T1.lo(), T0.hi(), Lit(6), T0.hi())  # a*65
+        e("v_add_u32", T0.hi(), T1.lo(), T0.lo())               # a*65 + b
         e("v_lshl_add_u32", XHW, T0.hi(), Lit(4), SG.TILE)
         e("v_and_b32", T1.lo(), Lit(0x38), LANE)                # g8
-        e("v_lshl_add_u32", T1.lo(), T0.lo(), Lit(6), T1.lo())  # b*64 + g8
+        e("v_lshl_add_u32", T1.hi(), T0.lo(), Lit(6), T0.lo())  # b*65
+        e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
-        e("v_lshlrev_b32", T1.hi(), Lit(4), T0.lo())            # b << 4
-        e("v_or_b32", XLW, XLW, T1.hi())
         e("v_and_b32", T0.lo(), Lit(1), LANE)
         e("v_sub_u32", EREG, Lit(1), T0.lo())
         if self.fair:
@@ -667,10 +666,10 @@ class Gen:
             if q < 2:
                 for m in range(16): self.ds_write("ds_write_b64", L8T, V(A[q] + 2 * m, 2), offset=512 * m)
             else:
-                for j in range(16): self.ds_read("ds_read_b64", OWN[j], L8T, offset=8192 + 512 * j)
+                for j in range(16): self.ds_read("ds_read_b64", OWN[j], L8T, offset=BODY + 512 * j)
             for m in range(8):
-                self.ds_read("ds_read_b64", V(D[q] + 4 * m, 2), RA[m], offset=8192 if q == 2 else 0)
-                self.ds_read("ds_read_b64", V(D[q] + 4 * m + 2, 2), RA[m + 8], offset=8192 if q == 2 else 0)
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m, 2), RA[m], offset=BODY if q == 2 else 0)
+                self.ds_read("ds_read_b64", V(D[q] + 4 * m + 2, 2), RA[m + 8], offset=BODY if q == 2 else 0)
 
         def digits(q):
             chains = []
@@ -731,7 +730,7 @@ class Gen:
             tmp = [(V(X + 4 * k, 2), V(X + 4 * k + 2, 2)) for k in range(4)] if nch == 4 else [(V(X, 2), V(X + 2, 2)), (T0, T1)]
             CUR = [V(X + 16 + 2 * j, 2) for j in range(16)]                      # body words (column 2): X[4..11]
             if col == 2:
-                for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=8192 + 512 * j)
+                for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=BODY + 512 * j)
 
             def upd(m, half, k):
                 j = m + 8 * half
@@ -741,7 +740,7 @@ class Gen:
                     self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k])
                 else:
                     self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tmp[k][0], tmp[k][1], CARRY[k])
-                    self.ds_write("ds_write_b64", L8T, CUR[j], offset=8192 + 512 * j)
+                    self.ds_write("ds_write_b64", L8T, CUR[j], offset=BODY + 512 * j)
             chains = []
             for m in range(8):
                 for half in range(2):
@@ -779,7 +778,7 @@ class Gen:
                 if q < 2: src = V(A[q] + 2 * m, 2)
                 else:
                     src = V(X + 2 * m, 2)
-                    self.ds_read("ds_read_b64", src, L8T, offset=8192 + 512 * m)
+                    self.ds_read("ds_read_b64", src, L8T, offset=BODY + 512 * m)
                     self.lg_wait(self.regs(src))
                 self.gstore("global_store_dwordx2", L8 if m < 8 else T0.lo(), src, SG.KP0, offset=512 * (m & 7))
         self.vm_wait_all()

@@ -12,8 +12,8 @@ the GLWE in LDS.  Arithmetic, operation order and results are those of trace_lds
 
     python3 tools/asmgen/trgen.py --out temp-fhe-transciphering_amd/csrc      (tx_trace_asm.inc + clobbers)
 
-LDS image (k_extract_trace4 / k_trace4 in tx_br2.hpp): compact twiddles at 0 (9 088 B), then per wave 32 KiB:
-8 KiB unpadded transpose tile (= ring slot of that wave) + the GLWE, 3 x 1024 torus words in natural order.
+LDS image (k_extract_trace4 / k_trace4 in tx_br2.hpp): compact twiddles at 0 (9 088 B), then per wave 32 896 B:
+8 320-byte transpose tile of pitch 65 (= ring slot of that wave) + the GLWE, 3 x 1024 torus words in natural order.
 
 Register map (VGPR): 0..15 as brgen.py (4: DMA source offset, 8: top-level tie mask, 9: gather index of m = 0),
 16..19 ring slot read addresses, 20..31 temporaries, P0 32..63 / P1 64..95 / P2 96..127 (digit polynomials of three
@@ -37,9 +37,9 @@ DC = 128
 K = [160, 192]
 GA = [V(224 + m) for m in range(16)]
 GS = [V(240 + m) for m in range(16)]
-WAVE_LDS = 32768
+WAVE_LDS = brgen.BODY + 3 * 8192           # per wave: padded tile (8 320 B, = its ring slot) + the GLWE
 ABL = os.environ.get("TR_ABL", "")        # timing-only ablations of the key pass (D no DMA, B no barriers, R no slot reads, A no AGPR reads, M no MAC): outputs invalid
-GL = 8192                                  # the GLWE follows the tile
+GL = brgen.BODY                            # the GLWE follows the tile
 
 
 class TS:      # scalar registers of this loop (constants at 48..58 and carries at 88..95 as brgen)
@@ -148,13 +148,13 @@ class TraceGen(Gen):
         e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
         e("v_add_u32", TWBA, Lit(brgen.TWB), TWBA)
         e("v_lshrrev_b32", T0.hi(), Lit(3), LANE)
-        e("v_lshl_add_u32", T0.hi(), T0.hi(), Lit(6), T0.lo())
+        e("v_lshl_add_u32", T1.lo(), T0.hi(), Lit(6), T0.hi())  # a*65 (tile pitch: brgen.PITCH)
+        e("v_add_u32", T0.hi(), T1.lo(), T0.lo())               # a*65 + b
         e("v_lshl_add_u32", XHW, T0.hi(), Lit(4), TS.TILE)
         e("v_and_b32", T1.lo(), Lit(0x38), LANE)
-        e("v_lshl_add_u32", T1.lo(), T0.lo(), Lit(6), T1.lo())
+        e("v_lshl_add_u32", T1.hi(), T0.lo(), Lit(6), T0.lo())  # b*65
+        e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), TS.TILE)
-        e("v_lshlrev_b32", T1.hi(), Lit(4), T0.lo())
-        e("v_or_b32", XLW, XLW, T1.hi())
         e("v_and_b32", T0.lo(), Lit(1), LANE)
         e("v_lshlrev_b32", TIE, Lit(AUTO_B - 1), T0.lo())       # tie_mask: (lane & 1) << 12
         for s_ in range(4):
