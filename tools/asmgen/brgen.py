@@ -12,14 +12,14 @@ kernel with the oracle on the GPU.
 
 Register map (VGPR):
     0 lane          1 tile + lane*8      2 tile + lane*16     3 lane*16 (twiddle row / key offset)
-    4 lane*16+4096  5 pass-B twiddle     6 xchg_hi store      7 xchg_lo store (xor r<<4)
+    4 lane*16+4096  5 pass-B twiddle     6 xchg_hi store      7 xchg_lo store
     8 e = 1-(lane&1)                     9 lane*8 (epilogue)  10,11 next mask element / hb, lb8
     12:13, 14:15 temporaries T0, T1
     16..47 A0   48..79 A1   (mask polynomials of the accumulator, 16 x u64 each)
     80..111 D0  112..143 D1  144..175 D2   (digit polynomials -> their transforms, 8 complex each)
     176..207 F  (Fourier accumulator of one column; rotation addresses + sign masks before the MAC)
     208..255 X  (key ring in the MAC; twiddles + spare quad in the transforms; body words in the rotation)
-SGPR: see `SG` below.  LDS image: tx_br2.hpp (twiddles at 0, per wave: 8 KiB unpadded tile + 8 KiB body).
+SGPR: see `SG` below.  LDS image: tx_br2.hpp (twiddles at 0, per wave: 8 320-byte tile of pitch 65 complex + 8 KiB body).
 """
 import os
 import struct
@@ -386,7 +386,7 @@ class Gen:
                 v[k], spare = spare, v[k]
         return v, spare
 
-    # ---------------------------------------------------------------- LDS tile exchanges (unpadded, tx_br2.hpp)
+    # ---------------------------------------------------------------- LDS tile exchanges (tile of pitch 65 complex, tx_br2.hpp)
     def xchg_hi_write(self, v):
         if "X" in ABL: return
         for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
