@@ -127,12 +127,25 @@ class Gen:
         if self.buf is None: self.p.comment(t)
 
     def chain(self, fn, *args):
-        """record the instructions fn(*args) emits, without processing them"""
-        assert self.buf is None
-        self.buf = []
+        """record the instructions fn(*args) emits, without processing them (re-entrant: a recorded function may
+        itself record and merge chains; what it merges lands in the outer recording)"""
+        saved, self.buf = self.buf, []
         fn(*args)
-        b, self.buf = self.buf, None
+        b, self.buf = self.buf, saved
         return b
+
+    def merge_spaced(self, main, sparse):
+        """emit chain `main` with the instructions of `sparse` spread evenly through it"""
+        main, sparse = list(main), list(sparse)
+        k = max(1, len(main) // (len(sparse) + 1))
+        n = 0
+        for op, a, kw in main:
+            self.e(op, *a, **kw)
+            n += 1
+            if sparse and n % k == 0:
+                o2, a2, k2 = sparse.pop(0)
+                self.e(o2, *a2, **k2)
+        for o2, a2, k2 in sparse: self.e(o2, *a2, **k2)
 
     def merge(self, chains):
         """emit independent instruction chains round-robin (in-order issue: the neighbours cover each other's latency)"""
@@ -388,16 +401,16 @@ class Gen:
 
     # ---------------------------------------------------------------- LDS tile exchanges (tile of pitch 65 complex, tx_br2.hpp)
     def xchg_hi_write(self, v):
-        if "X" in ABL: return
+        if "X" in ABL or "w" in ABL: return
         for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
 
     def xchg_read(self, dst, swz):
         """row r of the tile, this lane's column (both exchanges read the same way; swz is kept for the call sites)"""
-        if "X" in ABL: return
+        if "X" in ABL or "r" in ABL: return
         for r in range(8): self.ds_read("ds_read_b128", dst[r], L16T, offset=PITCH * r)
 
     def xchg_lo_write(self, v):
-        if "X" in ABL: return
+        if "X" in ABL or "w" in ABL: return
         for r in range(8): self.ds_write("ds_write_b128", XLW, v[r], offset=16 * r)
 
     def load_tw(self, dst, row0, nrows, compact=False):

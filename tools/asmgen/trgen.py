@@ -56,6 +56,103 @@ class TraceGen(Gen):
         self.steps = steps                # debugging: fewer trace steps
         self.stop_after = stop_after      # debugging: leave the step after phase "G" (digits parked), "B" (body), "M0" ...
 
+    # ------------------------------------------------------------------ transforms of a wave that is alone on its SIMD
+    # A ds_write_b128 holds the CU's LDS store path for 13 cycles, and a wave waits at a store until the path takes it:
+    # with the four waves of the workgroup in the same pass, eight stores in a row cost a wave ~420 cycles (stamps
+    # inside the transforms, tools/substamps_trace.sh: stores 53 cycles each, loads 16) in which it issues nothing.
+    # Here the stores of polynomial p's exchange are spread through the butterflies of polynomial p + 1 (the next
+    # pass's first polynomial after the last one), so each store finds the path as free as four waves leave it; the
+    # loads follow the last store.  Every polynomial has its own spare quad.  Same arithmetic, same order per polynomial.
+    PIPE = os.environ.get("TR_PIPE", "1") != "0"
+
+    def _pipeline(self, items):
+        """items: (valu function, store function or None, load function or None) in program order"""
+        pend = None
+        for valu, store, load in items:
+            ch = self.chain(valu)
+            if pend:
+                self.merge_spaced(ch, pend[0])
+                pend[1]()                   # the loads in a row behind the last store (spreading them too measured the same)
+            else:
+                self.merge([ch])
+            pend = (self.chain(store), load) if store else None
+        assert pend is None
+
+    def inv3(self, polys, xq):
+        if not self.PIPE: return super().inv3(polys, xq)
+        tw, spares = xq[:8], [xq[8], xq[9], xq[10]]
+        home_lo = [min(q.i for q in polys[p]) for p in range(3)]
+        self.c("inverse x3 (stores of an exchange spread through the next polynomial's butterflies)")
+        self.substamp("inv3", 5)
+        self.load_tw(tw, 0, 7, compact=True)
+
+        def reread(p):
+            def f():
+                free = sorted(polys[p] + [spares[p]], key=lambda q: q.i)
+                polys[p], spares[p] = free[:8], free[8]
+                self.xchg_read(polys[p], swz=False)
+            return f
+
+        def valu(pas, p):
+            def f():
+                if pas == 2:
+                    self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spares[p], conj=True)
+                    if p == 2: self.load_tw(tw, 0, 8)               # the pass-A rows replace the pass-B rows after their last use
+                if pas == 1: self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spares[p], conj=True)
+                polys[p], spares[p] = self.dft8(polys[p], spares[p], -1)
+                if pas == 1: polys[p], spares[p] = self.home(polys[p], spares[p], home_lo[p], home_lo[p] + 32)
+            return f
+        items = []
+        for pas in (3, 2, 1):
+            for p in range(3):
+                st = None
+                if pas == 3: st = (lambda p=p: self.xchg_lo_write(polys[p]))
+                if pas == 2: st = (lambda p=p: self.xchg_hi_write(polys[p]))
+                items.append((valu(pas, p), st, reread(p) if st else None))
+        self._pipeline(items)
+        self.substamp("inv3", 2)
+        self.twist_consts(polys, spares[0], conj=True)
+        self.substamp("inv3", 3)
+        return polys, spares[0]
+
+    def fwd3(self, polys, xq, before_pass3=None):
+        if not self.PIPE: return super().fwd3(polys, xq, before_pass3)
+        assert before_pass3 is None
+        tw, spares = xq[:8], [xq[8], xq[9], xq[10]]
+        home_lo = [min(q.i for q in polys[p]) for p in range(3)]
+        self.c("forward x3 (stores of an exchange spread through the next polynomial's butterflies)")
+        self.substamp("fwd3", 5)
+        self.load_tw(tw, 0, 8)
+        self.twist_consts(polys, None, conj=False)
+        self.substamp("fwd3", 0)
+
+        def reread(p):
+            def f():
+                free = sorted(polys[p] + [spares[p]], key=lambda q: q.i)
+                polys[p], spares[p] = free[:8], free[8]
+                self.xchg_read(polys[p], swz=False)
+            return f
+
+        def valu(pas, p):
+            def f():
+                polys[p], spares[p] = self.dft8(polys[p], spares[p], +1)
+                if pas == 1:
+                    self.cmul_all([(polys[p][r], tw[r]) for r in range(8)])
+                    if p == 2: self.load_tw(tw, 0, 7, compact=True)
+                if pas == 2: self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)])
+                if pas == 3: polys[p], spares[p] = self.home(polys[p], spares[p], home_lo[p], home_lo[p] + 32)
+            return f
+        items = []
+        for pas in (1, 2, 3):
+            for p in range(3):
+                st = None
+                if pas == 1: st = (lambda p=p: self.xchg_hi_write(polys[p]))
+                if pas == 2: st = (lambda p=p: self.xchg_lo_write(polys[p]))
+                items.append((valu(pas, p), st, reread(p) if st else None))
+        self._pipeline(items)
+        self.substamp("fwd3", 3)
+        return polys, spares[0]
+
     # ------------------------------------------------------------------ LDS-DMA ring (see KeyRing in tx_kernels.hpp)
     def dma(self, j):
         """this wave's quarter of key polynomial j of the current pass -> ring slot j % 4 (two 1 KiB loads)"""
