@@ -428,7 +428,10 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // waves of the last workgroup shadow the last unit.  Bit-identical to k_extract_trace and the oracle.
 // ------------------------------------------------------------------------------------------
 constexpr size_t TR4_WAVE_BYTES = BR3_TILE_BYTES + (size_t)GL * sizeof(uint64_t);
-constexpr size_t LDS_BYTES_TR4 = BR3_TW_CPLX * sizeof(cplx) + WAVES * TR4_WAVE_BYTES;
+#ifndef TR4_EXTRA_SLOTS
+#define TR4_EXTRA_SLOTS 0      // ring mode experiments (TR_SLOTS of trgen.py): 8 KiB slots behind the last wave's GLWE
+#endif
+constexpr size_t LDS_BYTES_TR4 = BR3_TW_CPLX * sizeof(cplx) + WAVES * TR4_WAVE_BYTES + TR4_EXTRA_SLOTS * 8192;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g)

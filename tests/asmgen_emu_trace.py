@@ -21,7 +21,7 @@ import oracle_lib as O
 N, H, KP = 1024, 512, 3
 TW_BYTES = (8 * 64 + 7 * 8) * 16
 WAVE_LDS = 8320 + 3 * 8192             # padded tile + GLWE
-LDS_BYTES = TW_BYTES + 4 * WAVE_LDS
+LDS_BYTES = TW_BYTES + 4 * WAVE_LDS + 2 * 8192      # + two more ring slots (TR_SLOTS experiments)
 
 
 def main():

@@ -36,6 +36,15 @@ def test_generated_trace_loop_equals_oracle_four_waves(oracle):
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_trace_loop_variants_are_the_same_arithmetic(oracle):
+    """the generator's alternatives kept for experiments: keys streamed by every wave instead of the shared ring, a
+    deeper ring, transforms without the spread exchange stores"""
+    for env in ({"TR_KEYS": "global"}, {"TR_SLOTS": "6"}, {"TR_PIPE": "0"}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_trace.py"), "7"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, str(env) + r.stdout + r.stderr
+
+
 def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])

@@ -154,6 +154,12 @@ class TraceGen(Gen):
         return polys, spares[0]
 
     # ------------------------------------------------------------------ LDS-DMA ring (see KeyRing in tx_kernels.hpp)
+    NSLOT = int(os.environ.get("TR_SLOTS", 4))       # ring mode: slots 0..3 are the waves' tiles, further ones follow the last wave's GLWE
+
+    @staticmethod
+    def slot_off(s_):
+        return s_ * WAVE_LDS if s_ < 4 else 4 * WAVE_LDS + (s_ - 4) * 8192
+
     def dma(self, j):
         """this wave's quarter of key polynomial j of the current pass -> ring slot j % 4 (two 1 KiB loads)"""
         q, i, c = j // 9, (j // 3) % 3, j % 3
@@ -163,11 +169,11 @@ class TraceGen(Gen):
         e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
         e("s_addc_u32", TS.KP_.hi(), TS.PB.hi(), Lit(0))
         # destination: slot0 + (j % 4) * 32 KiB + wave * 2 KiB (wave-uniform, in M0)
-        e("s_add_u32", M0, TS.M0A, Lit((j % 4) * WAVE_LDS))
+        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(j % self.NSLOT)))
         e("s_nop", Lit(0))
         e("global_load_lds_dwordx4", DMAOFF, TS.KP_, offset=0)
         self.vmq.append({1000 + j})
-        e("s_add_u32", M0, TS.M0A, Lit((j % 4) * WAVE_LDS + 1024))
+        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(j % self.NSLOT) + 1024))
         e("s_nop", Lit(0))
         e("global_load_lds_dwordx4", DMAOFF2, TS.KP_, offset=0)      # no instruction offset on an LDS-DMA load: it would also move the LDS address
         self.vmq.append({1000 + j})
@@ -188,6 +194,22 @@ class TraceGen(Gen):
             e("s_cbranch_scc1", lab)
             e("s_sleep", Lit(self.SKEW))
         self.p.label(lab)
+
+    # "ring": the workgroup's shared LDS ring (default); "global": every wave streams the key polynomials into registers
+    # itself.  Measured equal (14.1 ms standalone, any ring depth from 4 to 6 slots): streaming asks the CU's vector-memory
+    # path (64 B/clk) for 32 KiB per polynomial time, four times what the ring does, and is bound there; the ring by
+    # its per-polynomial issue costs.  Without any key loads the kernel takes 11.4 ms.
+    KEYS = os.environ.get("TR_KEYS", "ring")
+
+    def key_load(self, j, dst):
+        """key polynomial j of the current pass -> the eight quads dst (F-layout rows of 1 KiB, as the bootstrap key in brgen)"""
+        q, i, c = j // 9, (j // 3) % 3, j % 3
+        off = ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
+        e = self.e
+        e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
+        e("s_addc_u32", TS.KP_.hi(), TS.PB.hi(), Lit(0))
+        for r in range(8):
+            self.gload("global_load_dwordx4", dst[r], L16 if r < 4 else DMAOFF, TS.KP_, offset=(r & 3) * 1024)
 
     def ring_barrier(self, need=None):
         """this wave's LDS traffic done and (need: key polynomial) its DMA landed, then the workgroup barrier"""
@@ -238,8 +260,11 @@ class TraceGen(Gen):
         e("v_lshl_add_u32", L16T, LANE, Lit(4), TS.TILE)
         e("v_lshlrev_b32", L16, Lit(4), LANE)
         e("s_lshl_b32", TS.T, TS.WAVE, Lit(11))                 # wave * 2048
-        e("v_add_u32", DMAOFF, TS.T, L16)                       # (wave * 128 + lane) * 16
-        e("v_add_u32", DMAOFF2, Lit(1024), DMAOFF)              # second half: 64 complex further
+        if self.KEYS == "global":
+            e("v_add_u32", DMAOFF, Lit(4096), L16)              # rows 4..7 of a key polynomial
+        else:
+            e("v_add_u32", DMAOFF, TS.T, L16)                   # (wave * 128 + lane) * 16
+            e("v_add_u32", DMAOFF2, Lit(1024), DMAOFF)          # second half: 64 complex further
         e("s_add_u32", TS.M0A, TS.SLOT0, TS.T)                  # slot 0 + wave * 2 KiB
         e("v_and_b32", T0.lo(), Lit(7), LANE)
         e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
@@ -350,20 +375,15 @@ class TraceGen(Gen):
             KS = [[quad(K[b], r) for r in range(8)] for b in range(2)]
             DCq = [quad(DC, r) for r in range(8)]
             NK = 2 * AUTO_L * KP
-            # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
-            # barrier per two polynomials was measured slower: one pair of lookahead does not cover the DMA latency).
-            self.ring_barrier()                                  # every wave is done with its tile
-            for j in range(3): self.dma(j)
-
             def load_dc(g):
                 if "A" in ABL: return
                 for r in range(8):
                     for k in range(4):
                         self.e("v_accvgpr_read_b32", V(DCq[r].i + k), A((g * 8 + r) * 4 + k))
 
-            def mac(j, r):
+            def mac(j, r, KS):
                 if "M" in ABL: return
-                c, g, d, first = j % KP, KS[j % 2][r], DCq[r], j < KP
+                c, g, d, first = j % KP, KS[j % len(KS)][r], DCq[r], j < KP
                 re0 = Lit(0, f64=0.0) if first else qre(Fq[c][r])
                 im0 = Lit(0, f64=0.0) if first else qim(Fq[c][r])
                 self.e("v_fma_f64", qre(Fq[c][r]), qre(d), qre(g), re0)
@@ -371,18 +391,39 @@ class TraceGen(Gen):
                 self.e("v_fma_f64", qre(Fq[c][r]), -qim(d), qim(g), qre(Fq[c][r]))
                 self.e("v_fma_f64", qim(Fq[c][r]), qim(d), qre(g), qim(Fq[c][r]))
 
-            def macs(j):
+            def macs(j, KS):
                 if j % KP == 0: load_dc(j // KP)
-                for r in range(0, 8, 2): self.merge([self.chain(mac, j, r), self.chain(mac, j, r + 1)])
-            for j in range(NK):
-                self.ring_barrier(need=j)                        # polynomial j landed everywhere; slot (j - 1) % 4 is free
-                if "R" not in ABL:
-                    for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SL[j % 4], offset=1024 * r)
-                if j + 3 < NK: self.dma(j + 3)
-                if j >= 1: macs(j - 1)                           # covers the slot read above
-            macs(NK - 1)
-            self.ring_barrier()                                  # every wave has read the last slot: tiles free again
-            self.skew()
+                for r in range(0, 8, 2): self.merge([self.chain(mac, j, r, KS), self.chain(mac, j, r + 1, KS)])
+            if self.KEYS == "global":
+                # Every wave streams the 18 key polynomials of the pass into registers itself, three register sets
+                # (the two key sets + the gather tables' registers, free here), three polynomials in flight: no ring, no
+                # barrier, no LDS traffic in the pass (418 cycles per polynomial against 485 through the ring and 175 of
+                # arithmetic; the kernel as a whole takes the same time).
+                KS = KS + [[V(GA[0].i + 4 * r, 4) for r in range(4)] + [V(GS[0].i + 4 * r, 4) for r in range(4)]]
+                for j in range(3): self.key_load(j, KS[j % 3])
+                for j in range(NK):
+                    macs(j, KS)                                  # e() waits for the polynomial's loads at their first use
+                    if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
+            else:
+                # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
+                # barrier per two polynomials was measured slower: one pair of lookahead does not cover the DMA latency).
+                self.ring_barrier()                              # every wave is done with its tile
+                NS = self.NSLOT
+                SLR = list(SL)
+                for k in range(4, NS):
+                    e("s_add_u32", TS.T, TS.SLOT0, Lit(self.slot_off(k)))
+                    e("v_add_u32", TMP[k - 4], TS.T, L16)
+                    SLR.append(TMP[k - 4])
+                for j in range(NS - 1): self.dma(j)
+                for j in range(NK):
+                    self.ring_barrier(need=j)                    # polynomial j landed everywhere; slot (j - 1) % NS is free
+                    if "R" not in ABL:
+                        for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SLR[j % NS], offset=1024 * r)
+                    if j + NS - 1 < NK: self.dma(j + NS - 1)
+                    if j >= 1: macs(j - 1, KS)                   # covers the slot read above
+                macs(NK - 1, KS)
+                self.ring_barrier()                              # every wave has read the last slot: tiles free again
+                self.skew()
             self.stamp(2)
             # ---- three inverse transforms together, then the accumulation into the GLWE
             xq = [quad(K[0], r) for r in range(8)] + [quad(K[1], r) for r in range(8)] + [quad(DC, r) for r in range(8)]
