@@ -38,6 +38,7 @@ struct tx_ctx {
     cplx *tw = nullptr, *tw256 = nullptr;
     int num_cus = 0;
     int trace_variant = 4;                  // k_extract_trace4 (generated trace loop); TX_TRACE_VARIANT=0: the hipcc kernel
+    int ss_variant = 4;                     // k_scheme_switch4 (generated body); TX_SS_VARIANT=0: the hipcc kernel
     int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4 forces a kernel
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
@@ -134,9 +135,14 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     c->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("TX_BR_VARIANT")) c->br_variant = atoi(e);
     if (const char *e = getenv("TX_TRACE_VARIANT")) c->trace_variant = atoi(e);
+    if (const char *e = getenv("TX_SS_VARIANT")) c->ss_variant = atoi(e);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TR4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TR4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the generated trace kernel"); delete c; return nullptr;
+        fail("tx_create: cannot reserve LDS for the generated trace / scheme-switching kernels"); delete c; return nullptr;
     }
     return c;
 }
@@ -376,6 +382,10 @@ static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint
 static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
 {
     ev_begin(c, F_SS);
+    if (c->ss_variant == 4)
+        hipLaunchKernelGGL(k_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, glev, ggsw_f,
+                           (int)(count * CBS_L), c->ss_f, c->tw);
+    else
     hipLaunchKernelGGL(k_scheme_switch, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, glev, ggsw_f,
                        (int)(count * CBS_L), c->ss_f, c->tw);
     ev_end(c);
@@ -393,6 +403,13 @@ static void run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw
 {
     run_ks(c, lwe_big, count, c->small);
     run_br(c, c->small, count, c->acc);
+    if (c->trace_variant == 4 && c->ss_variant == 4) {      // fused: the GLev element never leaves the workgroup's LDS
+        ev_begin(c, F_TRACE);                                // (reported under ms_trace; ms_scheme_switch stays 0)
+        hipLaunchKernelGGL(k_trace_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, c->acc, ggsw_f,
+                           (int)count, c->auto_f, c->auto_split_stride, c->ss_f, c->tw);
+        ev_end(c);
+        return;
+    }
     run_extract_trace(c, c->acc, count, c->glev);
     run_ss(c, c->glev, count, ggsw_f);
 }

@@ -433,24 +433,10 @@ constexpr size_t TR4_WAVE_BYTES = BR3_TILE_BYTES + (size_t)GL * sizeof(uint64_t)
 #endif
 constexpr size_t LDS_BYTES_TR4 = BR3_TW_CPLX * sizeof(cplx) + WAVES * TR4_WAVE_BYTES + TR4_EXTRA_SLOTS * 8192;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g)
+// a6: buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const  (as k_extract_trace),
+// written into the wave's GLWE region of LDS
+__device__ __forceinline__ void tr4_extract_to_lds(const uint64_t *a, int lvl, uint64_t *gl, int lane)
 {
-    extern __shared__ __align__(16) unsigned char lds[];
-    cplx *tw = reinterpret_cast<cplx *>(lds);
-    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
-    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    int unit = blockIdx.x * WAVES + wave;
-    const bool active = unit < count * CBS_L;       // idle waves of the last workgroup redo the last unit (in their
-    if (!active) unit = count * CBS_L - 1;          // own LDS): every wave takes part in the key ring's barriers
-    unsigned char *slot0 = lds + BR3_TW_CPLX * sizeof(cplx);
-    unsigned char *tile = slot0 + (size_t)wave * TR4_WAVE_BYTES;
-    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
-    const int ctx = unit / CBS_L, lvl = unit % CBS_L;
-    const uint64_t *a = acc + (size_t)ctx * GL;
-    // buf = acc * X^(-lvl); body[0] += 2^(63 - 2 level); extract@0; >> 10; LWE -> GLWE const  (as k_extract_trace)
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -459,14 +445,13 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
             uint64_t x = (s < N) ? a[q * N + s] : (uint64_t)0 - a[q * N + s - N];
             gl[q * N + j] = (j == 0) ? (x >> LOGN) : (uint64_t)0 - (((uint64_t)0 - x) >> LOGN);
         }
-    {
-        const uint64_t b0 = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
+    const uint64_t b0 = (a[2 * N + lvl] + ((uint64_t)1 << (63 - CBS_B * (lvl + 1)))) >> LOGN;
 #pragma unroll
-        for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
-    }
-    const uint32_t slot0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)slot0);
-    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
-    const uint32_t split_bytes = (uint32_t)(split_stride * sizeof(cplx));
+    for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
+}
+// a7: the generated trace loop on the GLWE behind `tile` (tools/asmgen/trgen.py)
+__device__ __forceinline__ void tr4_trace_asm(const cplx *auto_f, uint32_t split_bytes, int wave, uint32_t slot0_addr, uint32_t tile_addr)
+{
 #ifdef TXD_STAMPS_TRACE
     unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
     if ((threadIdx.x & 63) == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)LOGN;
@@ -486,6 +471,59 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
 #include "tx_trace_asm_clobbers.inc"
     );
 #endif
+}
+// a8 + a9: the generated scheme-switching body on the GLev element behind `tile` (tools/asmgen/ssgen.py)
+__device__ __forceinline__ void tr4_ss_asm(const cplx *ss_f, cplx *o, int wave, uint32_t slot0_addr, uint32_t tile_addr)
+{
+#ifdef TXD_STAMPS_SS
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
+    if ((threadIdx.x & 63) == 0 && dbg == txd_stamps) txd_stamps[6] = 1ull;
+    asm volatile(
+#include "tx_ss_asm_stamps.inc"
+        :
+        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(dbg)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#else
+    asm volatile(
+#include "tx_ss_asm.inc"
+        :
+        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#endif
+}
+// twiddles into LDS (compact image), then this wave's slice: returns the tile; slot0 = wave 0's tile
+__device__ __forceinline__ unsigned char *tr4_setup(unsigned char *lds, const cplx *tw_g, int &wave, unsigned char *&slot0)
+{
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    __syncthreads();
+    wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    slot0 = lds + BR3_TW_CPLX * sizeof(cplx);
+    return slot0 + (size_t)wave * TR4_WAVE_BYTES;
+}
+__device__ __forceinline__ uint32_t lds_addr(unsigned char *p)
+{
+    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)p);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    int wave; unsigned char *slot0;
+    unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
+    const int lane = threadIdx.x & 63;
+    int unit = blockIdx.x * WAVES + wave;
+    const bool active = unit < count * CBS_L;       // idle waves of the last workgroup redo the last unit (in their
+    if (!active) unit = count * CBS_L - 1;          // own LDS): every wave takes part in the key ring's barriers
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
+    tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
+    tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, lds_addr(slot0), lds_addr(tile));
     if (!active) return;
     uint64_t *o = glev + (size_t)unit * GL;
     const int lane2 = threadIdx.x & 63;
@@ -493,6 +531,51 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
     for (int q = 0; q < KP; q++)
 #pragma unroll
         for (int m = 0; m < 16; m++) o[q * N + lane2 + 64 * m] = gl[q * N + lane2 + 64 * m];
+}
+
+// ------------------------------------------------------------------------------------------
+// a8 + a9 with the generated body (tools/asmgen/ssgen.py -> tx_ss_asm.inc): k_scheme_switch with the explicit
+// schedule of the trace loop.  Same LDS image as k_extract_trace4 (the GLev element sits where that kernel keeps its
+// GLWE), same ring protocol: every wave takes part in every barrier, so idle waves of the last workgroup shadow the
+// last unit -- and store the same values to the same place as the wave that owns it.  Bit-identical to
+// k_scheme_switch and the oracle.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx *ss_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    int wave; unsigned char *slot0;
+    unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
+    const int lane = threadIdx.x & 63;
+    int unit = blockIdx.x * WAVES + wave;
+    if (unit >= units) unit = units - 1;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
+    const uint64_t *gp = glev + (size_t)unit * GL;
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) gl[q * N + lane + 64 * m] = gp[q * N + lane + 64 * m];
+    tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, lds_addr(slot0), lds_addr(tile));
+}
+
+// a6 + a7 + a8 + a9 in one kernel: the traced GLev element stays in the wave's LDS slice and goes straight into the
+// scheme switch -- no GLev round trip through HBM (24 KiB out and in per unit) and one workgroup start (twiddle image,
+// first loads) instead of two.  What run_cbs launches; the stage entry points keep the two kernels apart.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_trace_scheme_switch4(const uint64_t *acc, cplx *ggsw_f, int count, const cplx *auto_f, size_t split_stride,
+                            const cplx *ss_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    int wave; unsigned char *slot0;
+    unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
+    const int lane = threadIdx.x & 63;
+    int unit = blockIdx.x * WAVES + wave;
+    if (unit >= count * CBS_L) unit = count * CBS_L - 1;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
+    tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
+    const uint32_t slot0_addr = lds_addr(slot0), tile_addr = lds_addr(tile);
+    tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, slot0_addr, tile_addr);
+    tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, slot0_addr, tile_addr);
 }
 
 }  // namespace txd

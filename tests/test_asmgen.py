@@ -36,6 +36,12 @@ def test_generated_trace_loop_equals_oracle_four_waves(oracle):
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_generated_scheme_switch_equals_oracle_four_waves(oracle):
+    """tools/asmgen/ssgen.py: a workgroup of four emulated waves against txo_scheme_switch() + txo_ggsw_to_fourier()"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_ss.py"), "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
 def test_trace_loop_variants_are_the_same_arithmetic(oracle):
     """the generator's alternatives kept for experiments: keys streamed by every wave instead of the shared ring, a
     deeper ring, transforms without the spread exchange stores"""
@@ -49,7 +55,8 @@ def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "fftconst.py"), "--out", str(tmp_path)])
-    for f in ("tx_fft_consts.inc", "tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_fair.inc", "tx_br_asm_fair_stamps.inc", "tx_br_asm_clobbers.inc",
+    subprocess.check_call([sys.executable, os.path.join(GEN, "ssgen.py"), "--out", str(tmp_path)])
+    for f in ("tx_fft_consts.inc", "tx_ss_asm.inc", "tx_ss_asm_stamps.inc", "tx_br_asm.inc", "tx_br_asm_stamps.inc", "tx_br_asm_fair.inc", "tx_br_asm_fair_stamps.inc", "tx_br_asm_clobbers.inc",
               "tx_trace_asm.inc", "tx_trace_asm_stamps.inc", "tx_trace_asm_clobbers.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
@@ -70,8 +77,8 @@ def test_twist_constants_are_the_oracles(oracle):
 def test_register_budget_and_no_scratch():
     """the loop must fit 256 VGPRs with nothing in scratch: two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, trgen, gcn
-    for prog in (brgen.Gen().build(), trgen.TraceGen().build()):
+    import brgen, trgen, ssgen, gcn
+    for prog in (brgen.Gen().build(), trgen.TraceGen().build(), ssgen.SsGen().build()):
         top = 0
         for i in prog.ins:
             for x in i.a:

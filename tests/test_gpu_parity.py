@@ -429,6 +429,24 @@ def test_trace_kernels_agree(rig256, monkeypatch):
     assert np.array_equal(new[:2], r.octx.extract_trace(acc[:2]))
 
 
+def test_scheme_switch_kernels_agree(rig256, monkeypatch):
+    """k_scheme_switch4 (generated body, the default) and k_scheme_switch (hipcc) on a ragged launch: the same Fourier
+    GGSW rows bit for bit, and the oracle's on a sample"""
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(31)
+    glev = rng.integers(0, 1 << 63, (5, r.p.cbs_level, 3, 1024), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (5, r.p.cbs_level, 3, 1024), dtype=np.uint64)
+    new = r.eng.scheme_switch_fourier(glev)              # 35 units: the last workgroup has one idle wave
+    monkeypatch.setenv("TX_SS_VARIANT", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    old = e0.scheme_switch_fourier(glev)
+    e0.close()
+    assert np.array_equal(new.view(np.uint64), old.view(np.uint64))
+    want = r.octx.ggsw_to_fourier(r.octx.scheme_switch(glev[:2]))
+    assert np.array_equal(np.asarray(new).reshape(5, -1)[:2].view(np.uint64), np.asarray(want).reshape(2, -1).view(np.uint64))
+
+
 def test_large_instance_properties(rig768):
     """size 3 as this repo defines it (4096 values = 512 blocks, CTR): larger than one workspace chunk (128 blocks), so
     the batch is split; properties that need no oracle: exact decryption, block independence across a chunk boundary,

@@ -379,6 +379,7 @@ class Emu:
     def op_v_fma_f64(self, d, a, b, c): self.wr64(d, self.fma(self.rd64(a), self.rd64(b), self.rd64(c)))
     def op_v_rndne_f64(self, d, a): self.wr64(d, np.rint(self.rd64(a)))
     def op_v_cvt_f64_i32(self, d, a): self.wr64(d, self.rd32(a).view(np.int32).astype(np.float64))
+    def op_v_cvt_f64_u32(self, d, a): self.wr64(d, self.rd32(a).astype(np.float64))
 
     # ---- LDS (lgkmcnt, in order)
     def _lds_addr(self, a, offset): return (self.rd32(a).astype(np.int64) + offset)
@@ -458,16 +459,19 @@ class Emu:
     def op_global_load_dwordx4(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 4)
     def op_global_load_dwordx2(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 2)
 
-    def op_global_store_dwordx2(self, voff, src, sbase, offset=0):
+    def _gstore(self, voff, src, sbase, offset, nd):
         assert -4096 <= offset <= 4095
         addr = self._gaddr(voff, sbase, offset)
-        vals = [self.rd32(V(src.i + k)) for k in range(2)]
+        vals = [self.rd32(V(src.i + k)) for k in range(nd)]
 
         def apply(addr=addr, vals=vals):
             for l in range(64):
-                arr, o = self.gmem(int(addr[l]), 8)
-                arr[o:o + 8].view(np.uint32)[:] = [vals[0][l], vals[1][l]]
+                arr, o = self.gmem(int(addr[l]), 4 * nd)
+                arr[o:o + 4 * nd].view(np.uint32)[:] = [v[l] for v in vals]
         self.vmq.append(([], apply))
+
+    def op_global_store_dwordx2(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 2)
+    def op_global_store_dwordx4(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 4)
 
 
 def run_group(emus, prog):

@@ -50,6 +50,7 @@ class TS:      # scalar registers of this loop (constants at 48..58 and carries 
 
 class TraceGen(Gen):
     CC, CS = TS.KP_, S(44, 2)         # twist constants: the DMA pointer and C64:T are dead inside a transform
+    DIG_B, DIG_L = AUTO_B, AUTO_L     # the decomposition this loop uses (prologue constants)
 
     def __init__(self, steps=LOGN, stop_after=None, stamps=False):
         super().__init__(stamps=stamps, prio="")
@@ -160,10 +161,16 @@ class TraceGen(Gen):
     def slot_off(s_):
         return s_ * WAVE_LDS if s_ < 4 else 4 * WAVE_LDS + (s_ - 4) * 8192
 
+    @staticmethod
+    def key_off(j):
+        """byte offset of key polynomial j of a pass from the pass base: digit polynomial j // 3 = (mask polynomial q, level
+        i finest first), column j % 3; the key stores level 1 (coarsest) first"""
+        q, i, c = j // 9, (j // 3) % 3, j % 3
+        return ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
+
     def dma(self, j):
         """this wave's quarter of key polynomial j of the current pass -> ring slot j % 4 (two 1 KiB loads)"""
-        q, i, c = j // 9, (j // 3) % 3, j % 3
-        off = ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
+        off = self.key_off(j)
         e = self.e
         if "D" in ABL: return
         e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
@@ -203,8 +210,7 @@ class TraceGen(Gen):
 
     def key_load(self, j, dst):
         """key polynomial j of the current pass -> the eight quads dst (F-layout rows of 1 KiB, as the bootstrap key in brgen)"""
-        q, i, c = j // 9, (j // 3) % 3, j % 3
-        off = ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
+        off = self.key_off(j)
         e = self.e
         e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
         e("s_addc_u32", TS.KP_.hi(), TS.PB.hi(), Lit(0))
@@ -223,29 +229,38 @@ class TraceGen(Gen):
     # ------------------------------------------------------------------ decomposition (Decomp<13, 3>, finest level first)
     def digits3(self, x, sgn, outs, t, cy):
         """x: rotated torus word (pair, destroyed); outs: three f64 pairs (levels finest..top); t: 3 temporaries"""
+        self.digits_bl(x, sgn, outs, t, cy, AUTO_B, AUTO_L)
+
+    def digits_bl(self, x, sgn, outs, t, cy, B, L):
+        """signed decomposition Decomp<B, L> of tx_kernels.hpp (tfhe-rs SignedDecomposer), finest level first: x (pair,
+        destroyed; negated first where sgn is all ones) -> L f64 digits.  TS.C_1P24 holds the rounding constant
+        2^(63 - B L), TIE the top-level tie mask (lane & 1) << (B - 1).  B L > 32: the state spans both dwords at first."""
         lo, hi = x.lo(), x.hi()
         res, u, car = t
         e = self.e
-        e("v_xor_b32", lo, lo, sgn)
-        e("v_xor_b32", hi, hi, sgn)
-        e("v_sub_co_u32", lo, cy, lo, sgn)
-        e("v_subb_co_u32", hi, cy, hi, sgn, cy)
-        # init: ((x >> 24) + 1) >> 1 & (2^39 - 1)  ==  (x + 2^24) >> 25 (the carry out of bit 63 is dropped either way)
+        total = B * L
+        assert 32 < total < 64
+        if sgn is not None:
+            e("v_xor_b32", lo, lo, sgn)
+            e("v_xor_b32", hi, hi, sgn)
+            e("v_sub_co_u32", lo, cy, lo, sgn)
+            e("v_subb_co_u32", hi, cy, hi, sgn, cy)
+        # init: ((x >> (63 - B L)) + 1) >> 1 & (2^(B L) - 1)  ==  (x + 2^(63 - B L)) >> (64 - B L) (the carry out of bit 63 is dropped either way)
         e("v_add_co_u32", lo, cy, TS.C_1P24, lo)             # VOP3 (own carry register): no literal, the constant sits in an SGPR
         e("v_addc_co_u32", hi, cy, Lit(0), hi, cy)
-        e("v_alignbit_b32", lo, hi, lo, Lit(25))            # state bits 0..31 (hi >> 25 holds bits 32..38)
-        e("v_lshrrev_b32", hi, Lit(25), hi)
-        for lev in range(AUTO_L):
-            e("v_and_b32", res, Lit(0x1FFF), lo)
-            if lev == 0: e("v_alignbit_b32", lo, hi, lo, Lit(AUTO_B))       # 39 -> 26 bits: fits one dword from here on
-            else: e("v_lshrrev_b32", lo, Lit(AUTO_B), lo)
+        e("v_alignbit_b32", lo, hi, lo, Lit(64 - total))    # state bits 0..31 (hi >> (64 - B L) holds the rest)
+        e("v_lshrrev_b32", hi, Lit(64 - total), hi)
+        for lev in range(L):
+            e("v_and_b32", res, Lit((1 << B) - 1), lo)
+            if lev == 0: e("v_alignbit_b32", lo, hi, lo, Lit(B))       # B L - B <= 32 bits: fits one dword from here on
+            else: e("v_lshrrev_b32", lo, Lit(B), lo)
             e("v_add_u32", u, Lit(-1), res)
             e("v_or_b32", u, u, lo)
-            if lev == AUTO_L - 1: e("v_or_b32", u, u, TIE)
+            if lev == L - 1: e("v_or_b32", u, u, TIE)
             e("v_and_b32", u, u, res)
-            e("v_lshrrev_b32", car, Lit(AUTO_B - 1), u)
-            if lev < AUTO_L - 1: e("v_add_u32", lo, lo, car)
-            e("v_lshlrev_b32", car, Lit(AUTO_B), car)
+            e("v_lshrrev_b32", car, Lit(B - 1), u)
+            if lev < L - 1: e("v_add_u32", lo, lo, car)
+            e("v_lshlrev_b32", car, Lit(B), car)
             e("v_sub_u32", res, res, car)
             e("v_cvt_f64_i32", outs[lev], res)
 
@@ -278,7 +293,7 @@ class TraceGen(Gen):
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), TS.TILE)
         e("v_and_b32", T0.lo(), Lit(1), LANE)
-        e("v_lshlrev_b32", TIE, Lit(AUTO_B - 1), T0.lo())       # tie_mask: (lane & 1) << 12
+        e("v_lshlrev_b32", TIE, Lit(self.DIG_B - 1), T0.lo())   # tie_mask: (lane & 1) << (B - 1)
         for s_ in range(4):
             e("s_add_u32", TS.T, TS.SLOT0, Lit(s_ * WAVE_LDS))
             e("v_add_u32", SL[s_], TS.T, L16)
@@ -291,12 +306,71 @@ class TraceGen(Gen):
             b = f64bits(val)
             e("s_mov_b32", s_.lo(), Lit(b & 0xFFFFFFFF)); e("s_mov_b32", s_.hi(), Lit(b >> 32))
         e("s_mov_b32", SG.C_M4338, Lit((-0x43380000) & 0xFFFFFFFF))
-        e("s_mov_b32", TS.C_1P24, Lit(1 << 24))
+        e("s_mov_b32", TS.C_1P24, Lit(1 << (63 - self.DIG_B * self.DIG_L)))      # rounding constant of the decomposition
         e("s_mov_b32", TS.IDX, Lit(int(os.environ.get("TR_START", 0))))
         if self.stamps:
             for k in range(brgen.NSTAMP):
                 e("s_mov_b32", brgen.ST_ACC[k].lo(), Lit(0)); e("s_mov_b32", brgen.ST_ACC[k].hi(), Lit(0))
             self.stamp(None)
+
+    def key_pass(self):
+        """F[c] += D[j / 3] * key(j), j = 0..17, for the three columns c; D from the accumulation registers, the key
+        polynomials at PB + key_off(j).  Returns the quads of the three Fourier accumulators."""
+        e = self.e
+        Fq = [[quad(P[c], r) for r in range(8)] for c in range(KP)]
+        KS = [[quad(K[b], r) for r in range(8)] for b in range(2)]
+        DCq = [quad(DC, r) for r in range(8)]
+        NK = 2 * AUTO_L * KP
+        def load_dc(g):
+            if "A" in ABL: return
+            for r in range(8):
+                for k in range(4):
+                    self.e("v_accvgpr_read_b32", V(DCq[r].i + k), A((g * 8 + r) * 4 + k))
+
+        def mac(j, r, KS):
+            if "M" in ABL: return
+            c, g, d, first = j % KP, KS[j % len(KS)][r], DCq[r], j < KP
+            re0 = Lit(0, f64=0.0) if first else qre(Fq[c][r])
+            im0 = Lit(0, f64=0.0) if first else qim(Fq[c][r])
+            self.e("v_fma_f64", qre(Fq[c][r]), qre(d), qre(g), re0)
+            self.e("v_fma_f64", qim(Fq[c][r]), qre(d), qim(g), im0)
+            self.e("v_fma_f64", qre(Fq[c][r]), -qim(d), qim(g), qre(Fq[c][r]))
+            self.e("v_fma_f64", qim(Fq[c][r]), qim(d), qre(g), qim(Fq[c][r]))
+
+        def macs(j, KS):
+            if j % KP == 0: load_dc(j // KP)
+            for r in range(0, 8, 2): self.merge([self.chain(mac, j, r, KS), self.chain(mac, j, r + 1, KS)])
+        if self.KEYS == "global":
+            # Every wave streams the 18 key polynomials of the pass into registers itself, three register sets
+            # (the two key sets + the gather tables' registers, free here), three polynomials in flight: no ring, no
+            # barrier, no LDS traffic in the pass (418 cycles per polynomial against 485 through the ring and 175 of
+            # arithmetic; the kernel as a whole takes the same time).
+            KS = KS + [[V(GA[0].i + 4 * r, 4) for r in range(4)] + [V(GS[0].i + 4 * r, 4) for r in range(4)]]
+            for j in range(3): self.key_load(j, KS[j % 3])
+            for j in range(NK):
+                macs(j, KS)                                  # e() waits for the polynomial's loads at their first use
+                if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
+        else:
+            # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
+            # barrier per two polynomials was measured slower: one pair of lookahead does not cover the DMA latency).
+            self.ring_barrier()                              # every wave is done with its tile
+            NS = self.NSLOT
+            SLR = list(SL)
+            for k in range(4, NS):
+                e("s_add_u32", TS.T, TS.SLOT0, Lit(self.slot_off(k)))
+                e("v_add_u32", TMP[k - 4], TS.T, L16)
+                SLR.append(TMP[k - 4])
+            for j in range(NS - 1): self.dma(j)
+            for j in range(NK):
+                self.ring_barrier(need=j)                    # polynomial j landed everywhere; slot (j - 1) % NS is free
+                if "R" not in ABL:
+                    for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SLR[j % NS], offset=1024 * r)
+                if j + NS - 1 < NK: self.dma(j + NS - 1)
+                if j >= 1: macs(j - 1, KS)                   # covers the slot read above
+            macs(NK - 1, KS)
+            self.ring_barrier()                              # every wave has read the last slot: tiles free again
+            self.skew()
+        return Fq
 
     def step(self):
         e = self.e
@@ -371,59 +445,7 @@ class TraceGen(Gen):
             if s_: e("s_add_u32", TS.T, TS.T, TS.SPLIT)
             e("s_add_u32", TS.PB.lo(), TS.AUTO.lo(), TS.T)
             e("s_addc_u32", TS.PB.hi(), TS.AUTO.hi(), Lit(0))
-            Fq = [[quad(P[c], r) for r in range(8)] for c in range(KP)]
-            KS = [[quad(K[b], r) for r in range(8)] for b in range(2)]
-            DCq = [quad(DC, r) for r in range(8)]
-            NK = 2 * AUTO_L * KP
-            def load_dc(g):
-                if "A" in ABL: return
-                for r in range(8):
-                    for k in range(4):
-                        self.e("v_accvgpr_read_b32", V(DCq[r].i + k), A((g * 8 + r) * 4 + k))
-
-            def mac(j, r, KS):
-                if "M" in ABL: return
-                c, g, d, first = j % KP, KS[j % len(KS)][r], DCq[r], j < KP
-                re0 = Lit(0, f64=0.0) if first else qre(Fq[c][r])
-                im0 = Lit(0, f64=0.0) if first else qim(Fq[c][r])
-                self.e("v_fma_f64", qre(Fq[c][r]), qre(d), qre(g), re0)
-                self.e("v_fma_f64", qim(Fq[c][r]), qre(d), qim(g), im0)
-                self.e("v_fma_f64", qre(Fq[c][r]), -qim(d), qim(g), qre(Fq[c][r]))
-                self.e("v_fma_f64", qim(Fq[c][r]), qim(d), qre(g), qim(Fq[c][r]))
-
-            def macs(j, KS):
-                if j % KP == 0: load_dc(j // KP)
-                for r in range(0, 8, 2): self.merge([self.chain(mac, j, r, KS), self.chain(mac, j, r + 1, KS)])
-            if self.KEYS == "global":
-                # Every wave streams the 18 key polynomials of the pass into registers itself, three register sets
-                # (the two key sets + the gather tables' registers, free here), three polynomials in flight: no ring, no
-                # barrier, no LDS traffic in the pass (418 cycles per polynomial against 485 through the ring and 175 of
-                # arithmetic; the kernel as a whole takes the same time).
-                KS = KS + [[V(GA[0].i + 4 * r, 4) for r in range(4)] + [V(GS[0].i + 4 * r, 4) for r in range(4)]]
-                for j in range(3): self.key_load(j, KS[j % 3])
-                for j in range(NK):
-                    macs(j, KS)                                  # e() waits for the polynomial's loads at their first use
-                    if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
-            else:
-                # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
-                # barrier per two polynomials was measured slower: one pair of lookahead does not cover the DMA latency).
-                self.ring_barrier()                              # every wave is done with its tile
-                NS = self.NSLOT
-                SLR = list(SL)
-                for k in range(4, NS):
-                    e("s_add_u32", TS.T, TS.SLOT0, Lit(self.slot_off(k)))
-                    e("v_add_u32", TMP[k - 4], TS.T, L16)
-                    SLR.append(TMP[k - 4])
-                for j in range(NS - 1): self.dma(j)
-                for j in range(NK):
-                    self.ring_barrier(need=j)                    # polynomial j landed everywhere; slot (j - 1) % NS is free
-                    if "R" not in ABL:
-                        for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SLR[j % NS], offset=1024 * r)
-                    if j + NS - 1 < NK: self.dma(j + NS - 1)
-                    if j >= 1: macs(j - 1, KS)                   # covers the slot read above
-                macs(NK - 1, KS)
-                self.ring_barrier()                              # every wave has read the last slot: tiles free again
-                self.skew()
+            Fq = self.key_pass()
             self.stamp(2)
             # ---- three inverse transforms together, then the accumulation into the GLWE
             xq = [quad(K[0], r) for r in range(8)] + [quad(K[1], r) for r in range(8)] + [quad(DC, r) for r in range(8)]
