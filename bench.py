@@ -26,7 +26,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # Infinity Cache.  k_blind_rotate5 (two waves per SIMD, persistent; runs above 4 units per CU):
 # profiles/r2_final_pmc_{fetch,write}_size_blind_rotate5.csv (each XCD streams the key 4 times, once per unit of a wave);
 # k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
-BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (932189 * 2 + 208384) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
+BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930195 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
                          "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
 # per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
 # compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)

@@ -122,7 +122,8 @@ class SsGen(TraceGen):
             self.sel = i
             self.c("---- mask row %d: 18 key polynomials through the ring, inverse, round, forward, store" % i)
             e("s_mov_b32", TS.PB.lo(), TS.AUTO.lo()); e("s_mov_b32", TS.PB.hi(), TS.AUTO.hi())
-            if i == 1: self.vm_wait_all()                         # the stores of row 0 and row 2 are off the vector-memory counter before the ring's loads
+            # The stores of rows 0 and 2 may still be in flight under the second pass: they are OLDER than every ring load,
+            # so a counted wait for a ring load can only be satisfied late by them, never early (loads return in order).
             Fq = self.key_pass()
             self.stamp(1)
             xq = xq16 + [quad(DC, r) for r in range(8)]
