@@ -8,6 +8,7 @@ for spec in "$@"; do
   IFS=: read tag envs flags <<< "$spec"
   rm -rf build_exp/src_$tag && cp -r $C build_exp/src_$tag
   env $(echo $envs | tr ',' ' ') python tools/asmgen/trgen.py --out build_exp/src_$tag
+  env $(echo $envs | tr ',' ' ') python tools/asmgen/ssgen.py --out build_exp/src_$tag
 done
 for spec in "$@"; do
   IFS=: read tag envs flags <<< "$spec"

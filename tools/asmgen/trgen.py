@@ -168,19 +168,20 @@ class TraceGen(Gen):
         q, i, c = j // 9, (j // 3) % 3, j % 3
         return ((q * AUTO_L + (AUTO_L - 1 - i)) * KP + c) * 8192
 
-    def dma(self, j):
-        """this wave's quarter of key polynomial j of the current pass -> ring slot j % 4 (two 1 KiB loads)"""
+    def dma(self, j, slot=None):
+        """this wave's quarter of key polynomial j of the current pass -> ring slot (default j % NSLOT), two 1 KiB loads"""
         off = self.key_off(j)
         e = self.e
+        if slot is None: slot = j % self.NSLOT
         if "D" in ABL: return
         e("s_add_u32", TS.KP_.lo(), TS.PB.lo(), Lit(off))
         e("s_addc_u32", TS.KP_.hi(), TS.PB.hi(), Lit(0))
         # destination: slot0 + (j % 4) * 32 KiB + wave * 2 KiB (wave-uniform, in M0)
-        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(j % self.NSLOT)))
+        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(slot)))
         e("s_nop", Lit(0))
         e("global_load_lds_dwordx4", DMAOFF, TS.KP_, offset=0)
         self.vmq.append({1000 + j})
-        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(j % self.NSLOT) + 1024))
+        e("s_add_u32", M0, TS.M0A, Lit(self.slot_off(slot) + 1024))
         e("s_nop", Lit(0))
         e("global_load_lds_dwordx4", DMAOFF2, TS.KP_, offset=0)      # no instruction offset on an LDS-DMA load: it would also move the LDS address
         self.vmq.append({1000 + j})
@@ -205,7 +206,8 @@ class TraceGen(Gen):
     # "ring": the workgroup's shared LDS ring (default); "global": every wave streams the key polynomials into registers
     # itself.  Measured equal (14.1 ms standalone, any ring depth from 4 to 6 slots): streaming asks the CU's vector-memory
     # path (64 B/clk) for 32 KiB per polynomial time, four times what the ring does, and is bound there; the ring by
-    # its per-polynomial issue costs.  Without any key loads the kernel takes 11.4 ms.
+    # its per-polynomial issue costs.  Without any key loads the kernel takes 11.4 ms.  (Alternating the two - even
+    # polynomials through the ring, odd ones streamed - was slower than either: 14.7 ms.)
     KEYS = os.environ.get("TR_KEYS", "ring")
 
     def key_load(self, j, dst):
@@ -327,9 +329,9 @@ class TraceGen(Gen):
                 for k in range(4):
                     self.e("v_accvgpr_read_b32", V(DCq[r].i + k), A((g * 8 + r) * 4 + k))
 
-        def mac(j, r, KS):
+        def mac(j, r, kset):
             if "M" in ABL: return
-            c, g, d, first = j % KP, KS[j % len(KS)][r], DCq[r], j < KP
+            c, g, d, first = j % KP, kset[r], DCq[r], j < KP
             re0 = Lit(0, f64=0.0) if first else qre(Fq[c][r])
             im0 = Lit(0, f64=0.0) if first else qim(Fq[c][r])
             self.e("v_fma_f64", qre(Fq[c][r]), qre(d), qre(g), re0)
@@ -337,18 +339,19 @@ class TraceGen(Gen):
             self.e("v_fma_f64", qre(Fq[c][r]), -qim(d), qim(g), qre(Fq[c][r]))
             self.e("v_fma_f64", qim(Fq[c][r]), qim(d), qre(g), qim(Fq[c][r]))
 
-        def macs(j, KS):
+        def macs(j, kset):
             if j % KP == 0: load_dc(j // KP)
-            for r in range(0, 8, 2): self.merge([self.chain(mac, j, r, KS), self.chain(mac, j, r + 1, KS)])
+            for r in range(0, 8, 2): self.merge([self.chain(mac, j, r, kset), self.chain(mac, j, r + 1, kset)])
+        K2 = [V(GA[0].i + 4 * r, 4) for r in range(4)] + [V(GS[0].i + 4 * r, 4) for r in range(4)]     # the gather tables' registers, free here
         if self.KEYS == "global":
             # Every wave streams the 18 key polynomials of the pass into registers itself, three register sets
             # (the two key sets + the gather tables' registers, free here), three polynomials in flight: no ring, no
             # barrier, no LDS traffic in the pass (418 cycles per polynomial against 485 through the ring and 175 of
             # arithmetic; the kernel as a whole takes the same time).
-            KS = KS + [[V(GA[0].i + 4 * r, 4) for r in range(4)] + [V(GS[0].i + 4 * r, 4) for r in range(4)]]
+            KS = KS + [K2]
             for j in range(3): self.key_load(j, KS[j % 3])
             for j in range(NK):
-                macs(j, KS)                                  # e() waits for the polynomial's loads at their first use
+                macs(j, KS[j % 3])                           # e() waits for the polynomial's loads at their first use
                 if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
         else:
             # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
@@ -366,8 +369,8 @@ class TraceGen(Gen):
                 if "R" not in ABL:
                     for r in range(8): self.ds_read("ds_read_b128", KS[j % 2][r], SLR[j % NS], offset=1024 * r)
                 if j + NS - 1 < NK: self.dma(j + NS - 1)
-                if j >= 1: macs(j - 1, KS)                   # covers the slot read above
-            macs(NK - 1, KS)
+                if j >= 1: macs(j - 1, KS[(j - 1) % 2])       # covers the slot read above
+            macs(NK - 1, KS[(NK - 1) % 2])
             self.ring_barrier()                              # every wave has read the last slot: tiles free again
             self.skew()
         return Fq
