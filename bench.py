@@ -28,6 +28,9 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
 BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930195 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
                          "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
+# PMC pass over the same launch (tools/pmc_kernel.sh, profiles/r2c_pmc_sq_blind_rotate5.csv): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
+# = 0.401 per wave, two waves per SIMD
+BR_VALU_BUSY_PMC = {"k_blind_rotate5": 0.80}
 # per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
 # compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)
@@ -209,8 +212,13 @@ def main():
                          "fp64_valu": {"achieved_TFLOPs": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12,
                                        "peak_TFLOPs": FP64_PEAK_TFLOPS,
                                        "frac": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "vector_pipe_busy_pmc": (BR_VALU_BUSY_PMC.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
                          "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
-                                 "fp64_valu is the informative bound"},
+                                 "fp64_valu counts FP64 flops against the FMA peak at the nominal clock (half of this loop's FP64 "
+                                 "instructions are adds, a fifth of its vector instructions 32-bit, and the chip runs it at "
+                                 "1.85-1.9 GHz: power-bound); vector_pipe_busy_pmc is the fraction of cycles a SIMD's vector pipe "
+                                 "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES, "
+                                 "profiles/r2c_pmc_sq_blind_rotate5.csv)"},
             "kernel_ms_last_step": {k: round(v, 3) for k, v in last_timing.items() if k.startswith("ms_")},
             "setup_s": {"client_keygen": round(t_keygen, 2), "key_upload_and_transform": round(t_load, 3)},
         }
