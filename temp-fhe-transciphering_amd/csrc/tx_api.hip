@@ -405,7 +405,8 @@ static void run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw
     run_br(c, c->small, count, c->acc);
     if (c->trace_variant == 4 && c->ss_variant == 4) {      // fused: the GLev element never leaves the workgroup's LDS
         ev_begin(c, F_TRACE);                                // (reported under ms_trace; ms_scheme_switch stays 0)
-        hipLaunchKernelGGL(k_trace_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, c->acc, ggsw_f,
+        const int wgs = std::min(grid_for(count * CBS_L), c->num_cus * (getenv("TX_TRSS_WGS_PER_CU") ? atoi(getenv("TX_TRSS_WGS_PER_CU")) : 1));
+        hipLaunchKernelGGL(k_trace_scheme_switch4, dim3(wgs), dim3(256), LDS_BYTES_TR4, c->stream, c->acc, ggsw_f,
                            (int)count, c->auto_f, c->auto_split_stride, c->ss_f, c->tw);
         ev_end(c);
         return;

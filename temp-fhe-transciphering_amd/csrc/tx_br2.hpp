@@ -569,13 +569,20 @@ void k_trace_scheme_switch4(const uint64_t *acc, cplx *ggsw_f, int count, const 
     int wave; unsigned char *slot0;
     unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
     const int lane = threadIdx.x & 63;
-    int unit = blockIdx.x * WAVES + wave;
-    if (unit >= count * CBS_L) unit = count * CBS_L - 1;
     uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
-    tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
     const uint32_t slot0_addr = lds_addr(slot0), tile_addr = lds_addr(tile);
-    tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, slot0_addr, tile_addr);
-    tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, slot0_addr, tile_addr);
+    const uint32_t split_bytes = (uint32_t)(split_stride * sizeof(cplx));
+    // persistent workgroups: the twiddle image is built once; every wave of the workgroup makes the same number of
+    // passes (the ring's barriers), a wave past the end redoes the last unit and stores what its owner stores
+    const int total = count * CBS_L, per_pass = (int)gridDim.x * WAVES;
+#pragma unroll 1
+    for (int base = 0; base < total; base += per_pass) {
+        int unit = base + (int)blockIdx.x * WAVES + wave;
+        if (unit >= total) unit = total - 1;
+        tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
+        tr4_trace_asm(auto_f, split_bytes, wave, slot0_addr, tile_addr);
+        tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, slot0_addr, tile_addr);
+    }
 }
 
 }  // namespace txd
