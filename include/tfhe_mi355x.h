@@ -118,15 +118,18 @@ int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes, int ctr, i
 
 /* ---- measurement ---- */
 /* HIP-event time (ms) spent in each kernel family during the last tx_transcipher / tx_max_u16
- * call, measured on the stream the kernels were launched on, and the number of launches. */
+ * call, measured on the stream the kernels were launched on, and the number of launches.  The pipeline runs
+ * extraction, trace and scheme switch as one kernel: its time is reported under ms_trace and ms_scheme_switch
+ * stays 0 there (the stage entry points below run and time the two separately). */
 typedef struct {
     double ms_keyswitch, ms_blind_rotate, ms_trace, ms_scheme_switch, ms_lut_eval, ms_linear, ms_total;
     uint32_t n_keyswitch, n_blind_rotate, n_trace, n_scheme_switch, n_lut_eval, n_linear;
 } tx_timing;
 int tx_get_timing(tx_ctx *c, tx_timing *t);
 
-/* the forward-transform twiddle table [22][64] complex used by the kernels (for table pinning) */
-int tx_get_twiddles(tx_ctx *c, double *out /* 22*64*2 */);
+/* the forward-transform twiddle table [15][64] complex used by the kernels (for table pinning): eight pass-A rows
+ * with the lane part of the twist folded in, seven pass-B rows */
+int tx_get_twiddles(tx_ctx *c, double *out /* 15*64*2 */);
 
 #ifdef __cplusplus
 }
