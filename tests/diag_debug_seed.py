@@ -1,3 +1,4 @@
+"""diagnostic (uses the oracle, hence under tests/; not collected by pytest): rerun one failing block of a soak seed on GPU and oracle"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,4 +1,4 @@
-"""exploratory: full transcipher on the GPU, timing per kernel family, decrypt check"""
+"""diagnostic (uses the oracle's client-side helpers, hence under tests/; not collected by pytest): full transcipher on the GPU, timing per kernel family, decrypt check"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))

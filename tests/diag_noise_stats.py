@@ -1,4 +1,4 @@
-"""exploratory: distribution of the mod-switched rotation error entering the blind rotation"""
+"""diagnostic (uses the oracle, hence under tests/; not collected by pytest): distribution of the mod-switched rotation error entering the blind rotation"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
