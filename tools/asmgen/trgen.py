@@ -186,7 +186,7 @@ class TraceGen(Gen):
         e("global_load_lds_dwordx4", DMAOFF2, TS.KP_, offset=0)      # no instruction offset on an LDS-DMA load: it would also move the LDS address
         self.vmq.append({1000 + j})
 
-    SKEW = int(os.environ.get("TR_SKEW", 4))     # s_sleep units (64 cycles) of phase offset per wave index
+    SKEW = int(os.environ.get("TR_SKEW", 2))     # s_sleep units (64 cycles) of phase offset per wave index
 
     def skew(self):
         """Wave w waits w * SKEW * 64 cycles.  The four waves of a workgroup leave a barrier together and run the same
