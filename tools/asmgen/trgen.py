@@ -260,10 +260,9 @@ class TraceGen(Gen):
             e("v_or_b32", u, u, lo)
             if lev == L - 1: e("v_or_b32", u, u, TIE)
             e("v_and_b32", u, u, res)
-            e("v_lshrrev_b32", car, Lit(B - 1), u)
-            if lev < L - 1: e("v_add_u32", lo, lo, car)
-            e("v_lshlrev_b32", car, Lit(B), car)
-            e("v_sub_u32", res, res, car)
+            e("v_bfe_i32", car, u, Lit(B - 1), Lit(1))          # -carry (0 or -1)
+            if lev < L - 1: e("v_sub_u32", lo, lo, car)         # state += carry
+            e("v_lshl_add_u32", res, car, Lit(B), res)          # res -= carry << B
             e("v_cvt_f64_i32", outs[lev], res)
 
     # ------------------------------------------------------------------ the kernel
