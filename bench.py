@@ -31,9 +31,9 @@ BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930195 * 2 + 207872) * 1024, "k_bli
 # PMC pass over the same launch (tools/pmc_kernel.sh, profiles/r2c_pmc_sq_blind_rotate5.csv): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 # = 0.401 per wave, two waves per SIMD
 BR_VALU_BUSY_PMC = {"k_blind_rotate5": 0.80}
-# per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 -- the same 2712 in both kernels (ISA count of the
-# compiled k_blind_rotate; `tools/asmgen/brgen.py --count` for the generated loop: 1128 + 384 + 2 x 600)
-BR_F64_FLOP_PER_UNIT_STEP = 64 * (1128 + 384 + 2 * 600)
+# per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 (`tools/asmgen/brgen.py --count` for the generated loop:
+# 984 + 312 + 2 x 744 = 2784 flops in 2040 FP64 instructions; the same arithmetic in the hipcc kernels)
+BR_F64_FLOP_PER_UNIT_STEP = 64 * (984 + 312 + 2 * 744)
 
 
 def br_kernel_name(units, n_cus):

@@ -49,16 +49,17 @@ static inline void dft8(cplx v[8], int s)
     cplx a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
     cplx a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
     cplx a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
-    /* odd branch twiddles: b1 *= w8, b2 *= s*i, b3 *= w8^3, w8 = (1 + s i)/sqrt2 */
-    cplx t1, t2, t3;
+    /* odd branch: t1 = w8 b1, t2 = s i b2, t3 = w8^3 b3, w8 = (1 + s i)/sqrt2.  The factor sqrt(1/2) of t1 and t3 is
+     * not multiplied out: u1 = sqrt2 t1, u3 = sqrt2 t3, and it enters the last butterflies as a fused multiply-add */
+    cplx u1, t2, u3;
     if (s > 0) {
-        t1.re = (b1.re - b1.im) * SQRT_HALF; t1.im = (b1.re + b1.im) * SQRT_HALF;
-        t2.re = -b2.im;                      t2.im = b2.re;
-        t3.re = -((b3.re + b3.im) * SQRT_HALF); t3.im = (b3.re - b3.im) * SQRT_HALF;
+        u1.re = b1.re - b1.im;    u1.im = b1.re + b1.im;
+        t2.re = -b2.im;           t2.im = b2.re;
+        u3.re = -(b3.re + b3.im); u3.im = b3.re - b3.im;
     } else {
-        t1.re = (b1.re + b1.im) * SQRT_HALF; t1.im = (b1.im - b1.re) * SQRT_HALF;
-        t2.re = b2.im;                       t2.im = -b2.re;
-        t3.re = (b3.im - b3.re) * SQRT_HALF; t3.im = -((b3.re + b3.im) * SQRT_HALF);
+        u1.re = b1.re + b1.im;    u1.im = b1.im - b1.re;
+        t2.re = b2.im;            t2.im = -b2.re;
+        u3.re = b3.im - b3.re;    u3.im = -(b3.re + b3.im);
     }
     /* two 4-point DFTs */
     cplx p0, q0, p1, q1, d;
@@ -66,10 +67,13 @@ static inline void dft8(cplx v[8], int s)
     p0 = cadd(a0, a2); q0 = csub(a0, a2); p1 = cadd(a1, a3); d = csub(a1, a3);
     if (s > 0) { q1.re = -d.im; q1.im = d.re; } else { q1.re = d.im; q1.im = -d.re; }
     v[0] = cadd(p0, p1); v[4] = csub(p0, p1); v[2] = cadd(q0, q1); v[6] = csub(q0, q1);
-    /* odd outputs from t */
-    p0 = cadd(b0, t2); q0 = csub(b0, t2); p1 = cadd(t1, t3); d = csub(t1, t3);
+    /* odd outputs: p0 +- sqrt(1/2) (u1 + u3), q0 +- sqrt(1/2) (+-i)(u1 - u3) */
+    p0 = cadd(b0, t2); q0 = csub(b0, t2); p1 = cadd(u1, u3); d = csub(u1, u3);
     if (s > 0) { q1.re = -d.im; q1.im = d.re; } else { q1.re = d.im; q1.im = -d.re; }
-    v[1] = cadd(p0, p1); v[5] = csub(p0, p1); v[3] = cadd(q0, q1); v[7] = csub(q0, q1);
+    v[1].re = fma(p1.re, SQRT_HALF, p0.re);  v[1].im = fma(p1.im, SQRT_HALF, p0.im);
+    v[5].re = fma(-p1.re, SQRT_HALF, p0.re); v[5].im = fma(-p1.im, SQRT_HALF, p0.im);
+    v[3].re = fma(q1.re, SQRT_HALF, q0.re);  v[3].im = fma(q1.im, SQRT_HALF, q0.im);
+    v[7].re = fma(-q1.re, SQRT_HALF, q0.re); v[7].im = fma(-q1.im, SQRT_HALF, q0.im);
 }
 
 /* ---------------- tables ---------------- */

@@ -345,47 +345,48 @@ class Gen:
             spare = fr
         c = SG.C_SQH
         b1, b3 = b[1].q, b[3].q
+        # odd branch: u1 = sqrt2 w8 b1, u3 = sqrt2 w8^3 b3 (the factor sqrt(1/2) enters the last butterflies as an fma);
+        # each keeps one component in a temporary pair (T0 / T1) until the butterfly that consumes it
         if sign > 0:
-            # t1 = ((b1.x - b1.y) c, (b1.x + b1.y) c)
-            self.e("v_add_f64", tmp, qre(b1), -qim(b1))
+            self.e("v_add_f64", T0, qre(b1), -qim(b1))             # u1 = (b1.x - b1.y, b1.x + b1.y)
             self.e("v_add_f64", qim(b1), qre(b1), qim(b1))
-            self.e("v_mul_f64", qre(b1), tmp, c)
-            self.e("v_mul_f64", qim(b1), qim(b1), c)
-            t1 = Cx.of(b1)
-            t2 = b[2].mul_i()                                  # (-b2.y, b2.x)
-            # t3 = (-((b3.x + b3.y) c), (b3.x - b3.y) c)
-            self.e("v_add_f64", tmp, qre(b3), qim(b3))
+            u1 = Cx(T0, qim(b1), b1)
+            t2 = b[2].mul_i()                                      # (-b2.y, b2.x)
+            self.e("v_add_f64", T1, qre(b3), qim(b3))              # u3 = (-(b3.x + b3.y), b3.x - b3.y)
             self.e("v_add_f64", qim(b3), qre(b3), -qim(b3))
-            self.e("v_mul_f64", qre(b3), tmp, c)
-            self.e("v_mul_f64", qim(b3), qim(b3), c)
-            t3 = Cx(-qre(b3), qim(b3), b3)
+            u3 = Cx(-T1, qim(b3), b3)
         else:
-            # t1 = ((b1.x + b1.y) c, (b1.y - b1.x) c)
-            self.e("v_add_f64", tmp, qre(b1), qim(b1))
+            self.e("v_add_f64", T0, qre(b1), qim(b1))              # u1 = (b1.x + b1.y, b1.y - b1.x)
             self.e("v_add_f64", qim(b1), qim(b1), -qre(b1))
-            self.e("v_mul_f64", qre(b1), tmp, c)
-            self.e("v_mul_f64", qim(b1), qim(b1), c)
-            t1 = Cx.of(b1)
-            t2 = b[2].mul_mi()                                 # (b2.y, -b2.x)
-            # t3 = ((b3.y - b3.x) c, -((b3.x + b3.y) c))
-            self.e("v_add_f64", tmp, qim(b3), -qre(b3))
+            u1 = Cx(T0, qim(b1), b1)
+            t2 = b[2].mul_mi()                                     # (b2.y, -b2.x)
+            self.e("v_add_f64", T1, qim(b3), -qre(b3))             # u3 = (b3.y - b3.x, -(b3.x + b3.y))
             self.e("v_add_f64", qim(b3), qre(b3), qim(b3))
-            self.e("v_mul_f64", qre(b3), tmp, c)
-            self.e("v_mul_f64", qim(b3), qim(b3), c)
-            t3 = Cx(qre(b3), -qim(b3), b3)
+            u3 = Cx(T1, -qim(b3), b3)
         out = [None] * 8
 
-        def four(x0, x1, x2, x3, o0, o1, o2, o3, spare):
+        def bfly_scaled(x, y, spare):
+            """(x, y) -> (x + c y in x's quad, x - c y in `spare`), c = sqrt(1/2), one fma per component"""
+            assert x.q is not None and not x.re.neg and not x.im.neg
+            self.e("v_fma_f64", qre(spare), -y.re, c, x.re)
+            self.e("v_fma_f64", qim(spare), -y.im, c, x.im)
+            self.e("v_fma_f64", qre(x.q), y.re, c, x.re)
+            self.e("v_fma_f64", qim(x.q), y.im, c, x.im)
+            return Cx.of(x.q), Cx.of(spare), y.q
+
+        def four(x0, x1, x2, x3, o0, o1, o2, o3, spare, scaled=False):
             # p0 = x0 + x2; q0 = x0 - x2; p1 = x1 + x3; d = x1 - x3; q1 = +-i d; o0 = p0 + p1; o1 = p0 - p1; o2 = q0 + q1; o3 = q0 - q1
+            # (scaled: the last four use c p1 and c q1)
             p0, q0, fr = self.bfly(x0, x2, spare); spare = fr
             p1, d, fr = self.bfly(x1, x3, spare); spare = fr
             q1 = d.mul_i() if sign > 0 else d.mul_mi()
-            r0, r1, fr = self.bfly(p0, p1, spare); spare = fr
-            r2, r3, fr = self.bfly(q0, q1, spare); spare = fr
+            last = bfly_scaled if scaled else self.bfly
+            r0, r1, fr = last(p0, p1, spare); spare = fr
+            r2, r3, fr = last(q0, q1, spare); spare = fr
             out[o0], out[o1], out[o2], out[o3] = r0.q, r1.q, r2.q, r3.q
             return spare
         spare = four(a[0], a[1], a[2], a[3], 0, 4, 2, 6, spare)
-        spare = four(b[0], t1, t2, t3, 1, 5, 3, 7, spare)
+        spare = four(b[0], u1, t2, u3, 1, 5, 3, 7, spare, scaled=True)
         return out, spare
 
     def home(self, v, spare, lo, hi):
