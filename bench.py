@@ -26,7 +26,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # Infinity Cache.  k_blind_rotate5 (two waves per SIMD, persistent; runs above 4 units per CU):
 # profiles/r2_final_pmc_{fetch,write}_size_blind_rotate5.csv (each XCD streams the key 4 times, once per unit of a wave);
 # k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
-BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930195 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
+BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930104 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
                          "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
 # PMC pass over the same launch (tools/pmc_kernel.sh, profiles/r2c_pmc_sq_blind_rotate5.csv): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 # = 0.401 per wave, two waves per SIMD
