@@ -36,13 +36,6 @@ BR_VALU_BUSY_PMC = {"k_blind_rotate5": 0.80}
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (984 + 312 + 2 * 744)
 
 
-def br_kernel_name(units, n_cus):
-    """the dispatch rule of run_br (csrc/tx_api.hip): two-wave kernel above 4 units per CU, TX_BR_VARIANT overrides"""
-    v = os.environ.get("TX_BR_VARIANT")
-    if v is not None and v != "": return {5: "k_blind_rotate5", 4: "k_blind_rotate4"}.get(int(v), "k_blind_rotate")
-    return "k_blind_rotate5" if units > 4 * n_cus else "k_blind_rotate"
-
-
 def algorithmic_bytes_per_block(M):
     """stage-materialised model, keys once per stage per batch of M blocks"""
     return 1.847e9 + 0.556e9 / M
@@ -54,25 +47,33 @@ def br_launch_bytes(M, n):
 
 
 def cpu_baseline(n, seed, threads):
-    """C restatement of the reference's CPU path (oracle/, kind 'port') on a bounded sample of the
-    same workload: ONE AES block through rounds 10/9 plus FOUR bootstrapped rounds (about 20
-    core-seconds); a block has 9 such rounds, which are >99.9% of its cost."""
+    """C restatement of the reference's CPU path (oracle/, kind 'port') on a bounded sample of the same workload:
+    ONE AES block through rounds 10/9 plus FOUR (one thread: TWO) bootstrapped rounds (a block has 9 such rounds,
+    which are >99.9% of its cost), timed twice as SURVEY.md 8(d) asks: (i) on ONE thread -- the reference is `default = ["monothread"]`
+    (submission/cbs_lib/Cargo.toml:31-34) -- and (ii) on all host cores this job may use (the 128 bits of a block in
+    parallel).  About 20 core-seconds each.  `value` is leg (ii); leg (i) is reported under `one_thread`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     p = O.aes_tight(n=n)
     keys = O.Keys(p, seed=seed)
-    ctx = O.Ctx(keys, threads=threads)
     aes_key = bytes.fromhex("dc937b59892604f5a86ac96936cd7ff0")
     luts = keys.round_luts(aes_key)
     ct = bytes(range(16))
-    ctx.transcipher_partial(luts, ct, 0)          # warm threads / tables
-    t0 = time.time()
-    ctx.transcipher_partial(luts, ct, 4)
-    dt = time.time() - t0
-    ctx.close()
-    return {"value": 1.0 / (dt * 9 / 4), "unit": "AES blocks/s", "cores": threads, "kind": "port",
-            "sample": f"1 block x 4 of 9 bootstrapped rounds in {dt:.1f}s on {threads} threads, scaled x2.25"}
+
+    def leg(nthreads, rounds):
+        ctx = O.Ctx(keys, threads=nthreads)
+        ctx.transcipher_partial(luts, ct, 0)          # warm threads / tables
+        t0 = time.time()
+        ctx.transcipher_partial(luts, ct, rounds)
+        dt = time.time() - t0
+        ctx.close()
+        return {"value": 1.0 / (dt * 9 / rounds), "unit": "AES blocks/s", "cores": nthreads, "kind": "port",
+                "sample": f"1 block x {rounds} of 9 bootstrapped rounds in {dt:.1f}s on {nthreads} thread{'s' if nthreads > 1 else ''}, scaled x{9 / rounds:g}"}
+
+    out = leg(threads, 4)
+    out["one_thread"] = leg(1, 2)                     # about 10 s per round on one core
+    return out
 
 
 def main():
@@ -192,7 +193,7 @@ def main():
         _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
         br_avg_ms = br_ms[0] / max(1, br_launches[0])
-        br_kernel = br_kernel_name(m_local * 128, torch.cuda.get_device_properties(dev_index).multi_processor_count)
+        br_kernel = eng.last_blind_rotate_kernel()         # what run_br (csrc/tx_api.hip) launched, as the library reports it
         achieved = br_launch_bytes(m_local, args.n) / (br_avg_ms * 1e-3) / 1e9
         line = {
             "metric": "AES blocks transciphered/sec (medium instance)", "value": value, "unit": "AES blocks/s",
@@ -204,7 +205,7 @@ def main():
                        "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather"},
             "roofline": {"bound": "hbm", "kernel": br_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (BR_TRAFFIC_BYTES_8192[br_kernel] if (m_local * 128 == 8192 and args.n == 768) else None),
+                         "traffic": (BR_TRAFFIC_BYTES_8192.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
                          "avg_launch_ms": br_avg_ms, "launches": br_launches[0],
                          "algorithmic_bytes_per_launch": br_launch_bytes(m_local, args.n),
                          "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,

@@ -46,6 +46,8 @@ const char *tx_last_error(void);
 
 /* Replaces the key-conversion prologue of `main` (server_encrypted_aes_decryption.rs:640-687):
  * creates a context on HIP device `device`. */
+/* Experiment knobs (environment, read and validated ONCE here; an ill-formed or out-of-range value makes tx_create
+ * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU.  Unset = the product path. */
 tx_ctx *tx_create(const tx_params *p, int device);
 void    tx_destroy(tx_ctx *c);
 
@@ -126,6 +128,10 @@ typedef struct {
     uint32_t n_keyswitch, n_blind_rotate, n_trace, n_scheme_switch, n_lut_eval, n_linear;
 } tx_timing;
 int tx_get_timing(tx_ctx *c, tx_timing *t);
+/* name of the blind-rotation kernel the last launch used ("k_blind_rotate5", "k_blind_rotate", ...; "" before the
+ * first launch).  The dispatch is by launch size (and the TX_BR_VARIANT experiment knob, read once by tx_create):
+ * the measurement reports what ran, not what a copy of the rule predicts. */
+const char *tx_last_blind_rotate_kernel(const tx_ctx *c);
 
 /* the forward-transform twiddle table [15][64] complex used by the kernels (for table pinning): eight pass-A rows
  * with the lane part of the twist folded in, seven pass-B rows */

@@ -39,11 +39,14 @@ struct tx_ctx {
     int num_cus = 0;
     int trace_variant = 4;                  // k_extract_trace4 (generated trace loop); TX_TRACE_VARIANT=0: the hipcc kernel
     int ss_variant = 4;                     // k_scheme_switch4 (generated body); TX_SS_VARIANT=0: the hipcc kernel
-    int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4 forces a kernel
+    int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4|5 forces a kernel
+    int br5_wgs = 0;                        // 0: one workgroup per CU; TX_BR5_WGS caps the persistent grid (experiments)
+    int trss_wgs_per_cu = 1;                // TX_TRSS_WGS_PER_CU (experiments)
+    const char *last_br_kernel = "";        // what run_br launched last (tx_last_blind_rotate_kernel)
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
     // workspace (grown on demand)
-    size_t ws_blocks = 0;
+    size_t ws_blocks = 0, glev_bits = 0;
     uint64_t *st = nullptr, *sm = nullptr, *small = nullptr, *acc = nullptr, *glev = nullptr, *res = nullptr;
     cplx *ggsw_f = nullptr;
     uint8_t *d_bytes = nullptr, *d_ct = nullptr;
@@ -74,6 +77,19 @@ static cplx unit_root(long double num, long double den)
     const long double PI = 3.14159265358979323846264338327950288L;
     long double a = PI * num / den;
     return make_double2((double)cosl(a), (double)sinl(a));
+}
+
+// TX_* experiment knobs: read ONCE (tx_create), validated; a value that is not an integer in [lo, hi] is an error
+static int env_knob(const char *name, int lo, int hi, int &out)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return 0;
+    char *end = nullptr;
+    long v = strtol(e, &end, 10);
+    if (*end != 0 || v < lo || v > hi)
+        return fail(std::string("tx_create: ") + name + "=" + e + " is not an integer in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+    out = (int)v;
+    return 0;
 }
 
 static int upload_tables(tx_ctx *c)
@@ -107,10 +123,26 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { fail("tx_create: no such HIP device (the HIP path is mandatory, there is no CPU fallback)"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { fail("tx_create: hipSetDevice failed"); return nullptr; }
     tx_ctx *c = new tx_ctx();
-    c->p = *p; c->device = device;
+    c->p = *p; c->device = device; c->stream = nullptr;
     memset(&c->timing, 0, sizeof c->timing);
-    if (hipStreamCreate(&c->stream) != hipSuccess) { fail("tx_create: hipStreamCreate failed"); delete c; return nullptr; }
-    if (upload_tables(c) != 0) { delete c; return nullptr; }
+    // every failure below releases what was created so far (stream, tables): tx_destroy tolerates a partial context
+    if (hipStreamCreate(&c->stream) != hipSuccess) { c->stream = nullptr; fail("tx_create: hipStreamCreate failed"); tx_destroy(c); return nullptr; }
+    if (upload_tables(c) != 0) { tx_destroy(c); return nullptr; }
+    // experiment knobs, parsed once and validated here (behind the stream and the tables, so that a bad value also
+    // exercises the release of a half-built context)
+    if (env_knob("TX_BR_VARIANT", 0, 5, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
+        env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
+        env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu)) { tx_destroy(c); return nullptr; }
+    {
+        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5);
+#ifdef TXD_WITH_BR3
+        ok = ok || c->br_variant == 3;
+#endif
+        if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4)) {
+            fail("tx_create: TX_BR_VARIANT must be 0, 4 or 5 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
+            tx_destroy(c); return nullptr;
+        }
+    }
     // the trace kernels park two polynomials per wave in LDS: more than the 64 KiB default
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TRACE) != hipSuccess ||
@@ -118,7 +150,7 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
                             (int)LDS_BYTES_TRACE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the trace kernels"); delete c; return nullptr;
+        fail("tx_create: cannot reserve LDS for the trace kernels"); tx_destroy(c); return nullptr;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
@@ -130,19 +162,16 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
                             (int)LDS_BYTES_BR5) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); delete c; return nullptr;
+        fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); tx_destroy(c); return nullptr;
     }
     c->num_cus = prop.multiProcessorCount;
-    if (const char *e = getenv("TX_BR_VARIANT")) c->br_variant = atoi(e);
-    if (const char *e = getenv("TX_TRACE_VARIANT")) c->trace_variant = atoi(e);
-    if (const char *e = getenv("TX_SS_VARIANT")) c->ss_variant = atoi(e);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the generated trace / scheme-switching kernels"); delete c; return nullptr;
+        fail("tx_create: cannot reserve LDS for the generated trace / scheme-switching kernels"); tx_destroy(c); return nullptr;
     }
     return c;
 }
@@ -152,19 +181,19 @@ static void free_ws(tx_ctx *c)
     hipFree(c->st); hipFree(c->sm); hipFree(c->small); hipFree(c->acc); hipFree(c->glev); hipFree(c->res);
     hipFree(c->ggsw_f); hipFree(c->d_bytes); hipFree(c->d_ct);
     c->st = c->sm = c->small = c->acc = c->glev = c->res = nullptr; c->ggsw_f = nullptr; c->d_bytes = c->d_ct = nullptr;
-    c->ws_blocks = 0;
+    c->ws_blocks = 0; c->glev_bits = 0;
 }
 
 extern "C" void tx_destroy(tx_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
     hipFree(c->tw); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    hipStreamDestroy(c->stream);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -212,6 +241,7 @@ static void timing_collect(tx_ctx *c)
     t.ms_total = 0; for (int i = 0; i < F_COUNT; i++) t.ms_total += ms[i];
 }
 extern "C" int tx_get_timing(tx_ctx *c, tx_timing *t) { if (!c || !t) return fail("tx_get_timing: null"); *t = c->timing; return 0; }
+extern "C" const char *tx_last_blind_rotate_kernel(const tx_ctx *c) { return c ? c->last_br_kernel : ""; }
 extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
 {
     if (!c || !out) return fail("tx_get_twiddles: null");
@@ -238,11 +268,19 @@ extern "C" int tx_debug_stamps(tx_ctx *c, unsigned long long *out16)
 }
 #endif
 
+// device buffer released on every exit path
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+};
+
 // ---- key loading (SRV_AES:640-687) ----
 static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst, int mode)
 {
-    uint64_t *tmp = nullptr;
-    HIP_OK(hipMalloc(&tmp, words * 8));
+    DevBuf buf;
+    if (buf.alloc(words * 8)) return fail("fwd_polys: hipMalloc failed");
+    uint64_t *tmp = (uint64_t *)buf.p;
     HIP_OK(hipMemcpyAsync(tmp, h_src, words * 8, hipMemcpyHostToDevice, c->stream));
     int npoly = (int)(words / N);
     hipLaunchKernelGGL(k_fwd_torus, dim3(grid_for(npoly)), dim3(256), LDS_BYTES, c->stream, tmp, d_dst, npoly, mode,
@@ -253,7 +291,6 @@ static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
-    HIP_OK(hipFree(tmp));
     return 0;
 }
 
@@ -286,14 +323,14 @@ extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t n_bsk, c
     if (fwd_polys(c, auto_keys, na, c->auto_f, 1)) return -1;
     if (fwd_polys(c, ss_key, ns, c->ss_f, 0)) return -1;
     {
-        uint64_t *tmp = nullptr;
-        HIP_OK(hipMalloc(&tmp, nk * 8));
+        DevBuf buf;
+        if (buf.alloc(nk * 8)) return fail("tx_load_eval_keys: hipMalloc failed");
+        uint64_t *tmp = (uint64_t *)buf.p;
         HIP_OK(hipMemcpyAsync(tmp, ksk, nk * 8, hipMemcpyHostToDevice, c->stream));
         int npoly = (int)(nk / KS_N);
         hipLaunchKernelGGL(k_fwd_torus256, dim3(grid_for(npoly)), dim3(256), 0, c->stream, tmp, c->ksk_f, npoly, c->tw256);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(c->stream));
-        HIP_OK(hipFree(tmp));
     }
     c->have_keys = true;
     return 0;
@@ -325,7 +362,7 @@ static int ensure_ws(tx_ctx *c, size_t nb)
     HIP_OK(hipMalloc(&c->sm, 4 * bits * BIG * 8));
     HIP_OK(hipMalloc(&c->small, bits * (c->p.n + 1) * 8));
     HIP_OK(hipMalloc(&c->acc, bits * GL * 8));
-    HIP_OK(hipMalloc(&c->glev, bits * CBS_L * GL * 8));
+    // (no GLev buffer: the fused kernel keeps the GLev element in LDS; run_cbs allocates one for the separate kernels)
     HIP_OK(hipMalloc(&c->ggsw_f, bits * CBS_L * KP * KP * H * sizeof(cplx)));
     HIP_OK(hipMalloc(&c->d_bytes, nb * 16));
     HIP_OK(hipMalloc(&c->d_ct, nb * 16));
@@ -352,20 +389,25 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 5 : 0);
     if (variant == 5) {
         size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
-        if (const char *e = getenv("TX_BR5_WGS")) wgs = std::min<size_t>(wgs, (size_t)std::max(1, atoi(e)));      // experiments only
+        if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
+        c->last_br_kernel = "k_blind_rotate5";
         hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc,
                            (int)count, (int)c->p.n, c->bsk_f, c->tw);
     } else if (variant == 4) {
+        c->last_br_kernel = "k_blind_rotate4";
         hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
                            (int)c->p.n, c->bsk_f, c->tw);
 #ifdef TXD_WITH_BR3
     } else if (variant == 3) {
+        c->last_br_kernel = "k_blind_rotate3";
         hipLaunchKernelGGL(k_blind_rotate3, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
                            (int)c->p.n, c->bsk_f, c->tw);
 #endif
-    } else
-    hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
-                       (int)c->p.n, c->bsk_f, c->tw);
+    } else {
+        c->last_br_kernel = "k_blind_rotate";
+        hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
+                           (int)c->p.n, c->bsk_f, c->tw);
+    }
     ev_end(c);
 }
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
@@ -399,20 +441,27 @@ static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t
     ev_end(c);
 }
 // KS + CBS of `count` big LWEs into Fourier GGSWs
-static void run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw_f)
+static int run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw_f)
 {
     run_ks(c, lwe_big, count, c->small);
     run_br(c, c->small, count, c->acc);
     if (c->trace_variant == 4 && c->ss_variant == 4) {      // fused: the GLev element never leaves the workgroup's LDS
         ev_begin(c, F_TRACE);                                // (reported under ms_trace; ms_scheme_switch stays 0)
-        const int wgs = std::min(grid_for(count * CBS_L), c->num_cus * (getenv("TX_TRSS_WGS_PER_CU") ? atoi(getenv("TX_TRSS_WGS_PER_CU")) : 1));
+        const int wgs = std::min(grid_for(count * CBS_L), c->num_cus * c->trss_wgs_per_cu);
         hipLaunchKernelGGL(k_trace_scheme_switch4, dim3(wgs), dim3(256), LDS_BYTES_TR4, c->stream, c->acc, ggsw_f,
                            (int)count, c->auto_f, c->auto_split_stride, c->ss_f, c->tw);
         ev_end(c);
-        return;
+        return 0;
+    }
+    if (c->glev_bits < count) {                              // the separate kernels (TX_TRACE_VARIANT / TX_SS_VARIANT = 0) pass the
+        HIP_OK(hipStreamSynchronize(c->stream));             // GLev through HBM: 172 KiB per bit, allocated only here
+        hipFree(c->glev); c->glev = nullptr; c->glev_bits = 0;
+        HIP_OK(hipMalloc(&c->glev, std::max(count, c->ws_blocks * 128) * CBS_L * GL * 8));
+        c->glev_bits = std::max(count, c->ws_blocks * 128);
     }
     run_extract_trace(c, c->acc, count, c->glev);
     run_ss(c, c->glev, count, ggsw_f);
+    return 0;
 }
 static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 4096 ? 4096 : g); }
 
@@ -439,7 +488,7 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
         hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 1);
         ev_end(c);
         for (int s = 1; s <= 8 && s <= rounds_done; s++) {      // SRV_AES:130-163
-            run_cbs(c, c->st, bits, c->ggsw_f);
+            if (run_cbs(c, c->st, bits, c->ggsw_f)) return -1;
             run_lut(c, c->ggsw_f, nb * 16, c->luts + (size_t)s * set_sz, mult_sz, 4, c->sm);
             ev_begin(c, F_LIN);
             hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 1);
@@ -447,7 +496,7 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
         }
         const uint64_t *fin = c->st;
         if (rounds_done >= 9) {                                  // SRV_AES:166-180
-            run_cbs(c, c->st, bits, c->ggsw_f);
+            if (run_cbs(c, c->st, bits, c->ggsw_f)) return -1;
             run_lut(c, c->ggsw_f, nb * 16, c->luts + (size_t)9 * set_sz, 0, 1, c->sm);
             fin = c->sm;
         }
@@ -480,7 +529,7 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
             ev_begin(c, F_LIN);
             hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 0);
             ev_end(c);
-            run_cbs(c, c->st, bits, c->ggsw_f);
+            if (run_cbs(c, c->st, bits, c->ggsw_f)) return -1;
             run_lut(c, c->ggsw_f, nb * 16, c->ctr_luts + (size_t)s * set_sz, mult_sz, s == 9 ? 1 : 3, c->sm);
         }
         ev_begin(c, F_LIN);
@@ -526,11 +575,6 @@ extern "C" int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_
 }
 
 // ---- stage entry points (host buffers) ----
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
-};
 #define STAGE_PROLOGUE(name)                                                    \
     if (!c || !c->have_keys) return fail(name ": context without keys");        \
     HIP_OK(hipSetDevice(c->device));                                            \
@@ -607,6 +651,11 @@ extern "C" int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes,
 }
 
 // ---- a12: max of n_values u16 (SRV_CMP:34-98, 203-351), log-depth tournament ----
+// A tournament level is processed in chunks of at most MAX_CHUNK_PAIRS pairs, so the circuit-bootstrapping workspace is
+// that of a 128-block transcipher chunk whatever n_values is (the Fourier GGSWs of one bit are 504 KiB: 32 768 values at
+// once would need 270 GB).  Chunking only splits batches: every pair sees the same operations in the same order.
+static const size_t MAX_CHUNK_PAIRS = 512;                  // 2 x 512 x 16 bits = 16 384 = CHUNK_BLOCKS x 128
+
 extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
 {
     if (!c || !lwe_bits || !out_lwe || n_values == 0) return fail("tx_max_u16: bad argument");
@@ -615,22 +664,27 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
     timing_reset(c);
     const size_t v16 = (size_t)16 * BIG;
     size_t cnt = n_values;
-    // CBS workspace sized in "blocks" of 128 bits
-    if (ensure_ws(c, (cnt * 16 + 127) / 128)) return -1;
+    if (cnt == 1) {                                         // nothing to compare (a rank holding one value in the sharded max)
+        if (out_lwe != lwe_bits) memcpy(out_lwe, lwe_bits, v16 * 8);
+        timing_collect(c);
+        return 0;
+    }
+    const size_t cp = std::min(cnt / 2, MAX_CHUNK_PAIRS);   // pairs per chunk
+    const size_t maxu = cp * 16;                            // cmux units per chunk
+    if (ensure_ws(c, (2 * cp * 16 + 127) / 128)) return -1;
     DevBuf cur, nxt, A, B, E, M0, M1, sela, selb;
-    if (cur.alloc(cnt * v16 * 8) || nxt.alloc(cnt * v16 * 8)) return fail("hipMalloc failed");
-    const size_t maxu = (cnt / 2) * 16;                 // cmux units per step
+    if (cur.alloc(cnt * v16 * 8) || nxt.alloc(((cnt + 1) / 2) * v16 * 8)) return fail("hipMalloc failed");
     if (A.alloc(maxu * GL * 8) || B.alloc(maxu * GL * 8) || E.alloc(maxu * GL * 8) || M0.alloc(maxu * GL * 8) ||
         M1.alloc(maxu * GL * 8) || sela.alloc(maxu * 16 * sizeof(int)) || selb.alloc(maxu * 16 * sizeof(int)))
         return fail("hipMalloc failed");
     HIP_OK(hipMemcpyAsync(cur.p, lwe_bits, cnt * v16 * 8, hipMemcpyHostToDevice, c->stream));
     uint64_t *pc = (uint64_t *)cur.p, *pn = (uint64_t *)nxt.p;
-    {   // selector tables, built ONCE for the first (largest) level: for scan step i (bit index i, MSB-first
-        // storage) unit (q, t) selects GGSW (2q) * 16 + i (operand a) or (2q + 1) * 16 + i (operand b).  A later
-        // level with fewer pairs uses the first `units` entries of each step's row: rows are maxu entries apart.
+    {   // selector tables, built ONCE for a full chunk: for scan step i (bit index i, MSB-first storage) unit (q, t)
+        // selects GGSW (2q) * 16 + i (operand a) or (2q + 1) * 16 + i (operand b) of the chunk.  A chunk with fewer
+        // pairs uses the first `units` entries of each step's row: rows are maxu entries apart.
         std::vector<int> ha(maxu * 16), hb(maxu * 16);
         for (int i = 0; i < 16; i++)
-            for (size_t q = 0; q < cnt / 2; q++)
+            for (size_t q = 0; q < cp; q++)
                 for (int t = 0; t < 16; t++) {
                     ha[(size_t)i * maxu + q * 16 + t] = (int)((2 * q) * 16 + i);
                     hb[(size_t)i * maxu + q * 16 + t] = (int)((2 * q + 1) * 16 + i);
@@ -640,31 +694,35 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
         HIP_OK(hipStreamSynchronize(c->stream));         // the host vectors go out of scope
     }
     while (cnt > 1) {
-        const size_t pairs = cnt / 2, units = pairs * 16, nx = pairs + (cnt & 1);
-        run_cbs(c, pc, 2 * pairs * 16, c->ggsw_f);
-        // operands as GLWEs: A[q][t] = value 2q bit t, B = value 2q+1 bit t: one strided launch each
-        hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, pc, (uint64_t *)A.p, (int)units, 2, 0);
-        hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, pc, (uint64_t *)B.p, (int)units, 2, 1);
-        HIP_OK(hipMemcpyAsync(E.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));   // e = a (SURVEY 3.2 fix)
-        for (int i = 15; i >= 0; i--) {                 // .rev(): least significant bit first
-            const int *sa = (const int *)sela.p + (size_t)i * maxu, *sb = (const int *)selb.p + (size_t)i * maxu;
-            ev_begin(c, F_LUT);
-            HIP_OK(hipMemcpyAsync(M0.p, E.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M0.p,
-                               (const uint64_t *)B.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? B : e
-            HIP_OK(hipMemcpyAsync(M1.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M1.p,
-                               (const uint64_t *)E.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? e : A
-            HIP_OK(hipMemcpyAsync(E.p, M0.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)E.p,
-                               (const uint64_t *)M1.p, c->ggsw_f, sa, (int)units, c->tw);    // a_i ? m1 : m0
-            ev_end(c);
+        const size_t all_pairs = cnt / 2, nx = all_pairs + (cnt & 1);
+        for (size_t p0 = 0; p0 < all_pairs; p0 += cp) {
+            const size_t pairs = std::min(cp, all_pairs - p0), units = pairs * 16;
+            const uint64_t *src = pc + 2 * p0 * v16;        // values 2 p0 .. 2 (p0 + pairs) - 1 of this level
+            if (run_cbs(c, src, 2 * pairs * 16, c->ggsw_f)) return -1;
+            // operands as GLWEs: A[q][t] = value 2q bit t, B = value 2q+1 bit t: one strided launch each
+            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, src, (uint64_t *)A.p, (int)units, 2, 0);
+            hipLaunchKernelGGL(k_lwe_to_glwe, dim3(ew_grid(units * GL)), dim3(256), 0, c->stream, src, (uint64_t *)B.p, (int)units, 2, 1);
+            hipMemcpyAsync(E.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);   // e = a (SURVEY 3.2 fix)
+            for (int i = 15; i >= 0; i--) {                 // .rev(): least significant bit first
+                const int *sa = (const int *)sela.p + (size_t)i * maxu, *sb = (const int *)selb.p + (size_t)i * maxu;
+                ev_begin(c, F_LUT);                         // (no early return between ev_begin and ev_end)
+                hipMemcpyAsync(M0.p, E.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
+                hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M0.p,
+                                   (const uint64_t *)B.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? B : e
+                hipMemcpyAsync(M1.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
+                hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M1.p,
+                                   (const uint64_t *)E.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? e : A
+                hipMemcpyAsync(E.p, M0.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
+                hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)E.p,
+                                   (const uint64_t *)M1.p, c->ggsw_f, sa, (int)units, c->tw);    // a_i ? m1 : m0
+                ev_end(c);
+            }
+            hipLaunchKernelGGL(k_extract0, dim3(ew_grid(units * BIG)), dim3(256), 0, c->stream, (const uint64_t *)E.p,
+                               pn + p0 * v16, (int)units);
+            HIP_OK(hipGetLastError());                      // sticky: also reports a failed copy or launch of the scan above
         }
-        hipLaunchKernelGGL(k_extract0, dim3(ew_grid(units * BIG)), dim3(256), 0, c->stream, (const uint64_t *)E.p, pn,
-                           (int)units);
-        if (cnt & 1) HIP_OK(hipMemcpyAsync(pn + pairs * v16, pc + (cnt - 1) * v16, v16 * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIP_OK(hipGetLastError());                      // levels are ordered by the stream: no host synchronisation
-        std::swap(pc, pn);
+        if (cnt & 1) HIP_OK(hipMemcpyAsync(pn + all_pairs * v16, pc + (cnt - 1) * v16, v16 * 8, hipMemcpyDeviceToDevice, c->stream));
+        std::swap(pc, pn);                                  // levels are ordered by the stream: no host synchronisation
         cnt = nx;
     }
     HIP_OK(hipMemcpyAsync(out_lwe, pc, v16 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -814,7 +872,7 @@ extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t 
             HIP_OK(hipStreamSynchronize(c->stream));       // host vectors are reused by the next chunk
             hipLaunchKernelGGL(k_lwe_gather_add, dim3(ew_grid((size_t)ns * BIG)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
                                (const int *)di0.p, (const int *)di1.p, (uint64_t *)t.p, ns);
-            run_cbs(c, (const uint64_t *)t.p, ns, c->ggsw_f);
+            if (run_cbs(c, (const uint64_t *)t.p, ns, c->ggsw_f)) return -1;
             hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,
                                (const int *)dc0.p, (const int *)df0.p, (uint64_t *)g0.p, nj);
             hipLaunchKernelGGL(k_build_glwe, dim3(ew_grid((size_t)nj * GL)), dim3(256), 0, c->stream, (const uint64_t *)pool.p,

@@ -342,6 +342,12 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // advance at the same rate and the eight units of a workgroup finish together.  LDS: twiddles + 8 x 16 KiB + counters.
 // ------------------------------------------------------------------------------------------
 constexpr int BR5_WAVES = 8;
+// Scratch: the generated loop clobbers all 256 vector registers, so hipcc keeps what is live across it (threadIdx.x,
+// and the vector register it needs for scalar spills) in a small scratch frame (private_segment_fixed_size = 92 bytes
+// per lane), stored once before and reloaded once after each UNIT (768 CMux steps).  The loop itself issues no scratch
+// instruction and its prologue drains vmcnt(0), so that traffic never sits next to the counted waits.  Taking the
+// lane id from v_mbcnt instead (nothing live in a VGPR) does not build: "cannot find enough VGPRs for wwm-regalloc".
+// tests/test_asmgen.py bounds the frame in the built code object and checks that the .inc files hold no scratch op.
 constexpr size_t LDS_BYTES_BR5 = BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WAVE_BYTES + BR5_WAVES * sizeof(uint32_t);
 
 // Persistent: G = gridDim.x workgroups (one per CU), wave w of workgroup b takes units w * G + b + k * 8 G, k = 0, 1, ...

@@ -143,13 +143,14 @@ int client_postprocess(int size, const char *in_name, const char *out_name)
 // ---------------- server stages ----------------
 tx_ctx *server_context(const Paths &p, const tx_params &prm)
 {   // SRV_AES:620-687
-    int dev = getenv("TX_DEVICE") ? atoi(getenv("TX_DEVICE")) : 0;
-    tx_ctx *c = tx_create(&prm, dev);
-    if (!c) throw std::runtime_error(std::string("tx_create: ") + tx_last_error());
+    // the key files are read and checked first: a truncated or foreign file is an error before any GPU work
     std::vector<uint64_t> bsk = read_words(p.io + "/public_keys/bsk.bin"), ksk = read_words(p.io + "/public_keys/ksk.bin"),
         au = read_words(p.io + "/public_keys/auto_keys.bin"), ss = read_words(p.io + "/public_keys/ss_key.bin");
     if (bsk.size() != txc_bsk_words(&prm) || ksk.size() != txc_ksk_words(&prm) || au.size() != txc_auto_words(&prm) ||
-        ss.size() != txc_ss_words(&prm)) { tx_destroy(c); throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set"); }
+        ss.size() != txc_ss_words(&prm)) throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set");
+    int dev = getenv("TX_DEVICE") ? atoi(getenv("TX_DEVICE")) : 0;
+    tx_ctx *c = tx_create(&prm, dev);
+    if (!c) throw std::runtime_error(std::string("tx_create: ") + tx_last_error());
     check(tx_load_eval_keys(c, bsk.data(), bsk.size(), ksk.data(), ksk.size(), au.data(), au.size(), ss.data(), ss.size()),
           "tx_load_eval_keys");
     return c;

@@ -38,7 +38,6 @@ struct ChaCha {
     }
     static bool os_entropy(uint8_t *dst, size_t len)
     {
-        if (getenv("TXC_TEST_NO_ENTROPY")) return false;           // test hook for the failure path only
         size_t got = 0;
         while (got < len) {
             ssize_t r = getrandom(dst + got, len - got, 0);

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--fhe_seed", type=int, default=99)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--n", type=int, default=768, help="LWE dimension (AES_TIGHT: 768)")
+    ap.add_argument("--values", type=int, default=0,
+                    help="use only the first VALUES u16 of the instance (a multiple of 8 and even): rehearses a per-GPU "
+                         "share with fewer ranks than the node has GPUs")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,6 +62,10 @@ def main():
 
     np.random.seed(args.seed)
     db = np.random.randint(0, 65536, size=DB_BOUND[args.size], dtype=np.uint16)
+    if args.values:
+        if args.values % 8 or args.values > len(db):
+            raise SystemExit("--values must be a multiple of 8 (whole AES blocks) within the instance")
+        db = db[: args.values]
     key = hashlib.sha256(str(args.seed).encode()).digest()[:16]
     iv = hashlib.sha256(b"iv" + str(args.seed).encode()).digest()[:16] if args.size else None
     pt = b"".join(int(v).to_bytes(2, "big") for v in db)
@@ -100,6 +107,7 @@ def main():
     res = txdist.transcipher_sharded(local_fn, ct, iv, rank, world, d)
     sync(); t["transcipher_s"] = time.perf_counter() - t0
     mine, n_local_values = kept["mine"], kept["n"] * 8
+    br_kernel = eng.last_blind_rotate_kernel()             # of this rank's share of the transcipher
 
     t0 = time.perf_counter()
     mx = txdist.max_sharded(lambda x: to_t(eng.max_u16(to_np(x))), mine, n_local_values, rank, world, d)
@@ -122,7 +130,7 @@ def main():
         checks = {"aes": bool(np.array_equal(got, db)), "max": got_max == max(vals), "inner_product": got_ip == exp_ip}
         ok = all(checks.values())
         print(json.dumps({"size": args.size, "values": n_values, "blocks": n_blocks, "ranks": world, "backend": args.backend,
-                          "checks": checks, **{k: round(v, 4) for k, v in t.items()}}), flush=True)
+                          "checks": checks, "blind_rotate_kernel": br_kernel, **{k: round(v, 4) for k, v in t.items()}}), flush=True)
     if d is not None:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
         d.broadcast(flag, src=0)

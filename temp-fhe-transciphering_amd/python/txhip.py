@@ -36,7 +36,8 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_load_round_luts", "tx_load_ctr_luts", "tx_transcipher", "tx_transcipher_partial", "tx_max_u16",
            "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
-           "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles"]
+           "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles",
+           "tx_last_blind_rotate_kernel"]
 
 _LIB = None
 
@@ -70,6 +71,8 @@ def lib():
         L.tx_stage_lut_eval.argtypes = [C.c_void_p, f64p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p]
         L.tx_get_timing.argtypes = [C.c_void_p, C.POINTER(TxTiming)]
         L.tx_get_twiddles.argtypes = [C.c_void_p, f64p]
+        L.tx_last_blind_rotate_kernel.restype = C.c_char_p
+        L.tx_last_blind_rotate_kernel.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -211,6 +214,9 @@ class Engine:
         t = TxTiming()
         self._chk(lib().tx_get_timing(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in TxTiming._fields_}
+
+    def last_blind_rotate_kernel(self):
+        return lib().tx_last_blind_rotate_kernel(self.h).decode()
 
     def twiddles(self):
         out = np.zeros(15 * 64 * 2, np.float64)

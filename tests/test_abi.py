@@ -100,3 +100,28 @@ def test_header_is_plain_c99(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)       # no GPU call: parameter table only
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_install_layout_for_the_reference_harness(tmp_path):
+    """`make install PREFIX=<root>/submission/target/release`: the ten stage names the
+    reference's harness runs (harness/run_submission.py:68-115) exist there, load their libraries from that directory
+    and honour the argv / exit-code contract (usage error -> 1, the two stub stages -> 0) without a GPU"""
+    import subprocess
+    prefix = tmp_path / "submission" / "target" / "release"
+    host = os.path.join(ROOT, "temp-fhe-transciphering_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "install", "PREFIX=" + str(prefix)])
+    stages = ["client_preprocess", "client_key_generation", "client_encode_encrypt", "server_preprocess_dataset",
+              "server_encrypted_aes_decryption", "server_encrypted_compute", "client_decrypt_decode_aes_decryption",
+              "client_postprocess_aes_decryption", "client_decrypt_decode", "client_postprocess"]
+    for s in stages:
+        assert os.access(prefix / s, os.X_OK), s
+    ldd = subprocess.run(["ldd", str(prefix / "server_encrypted_compute")], capture_output=True, text=True).stdout
+    for lib in ("libtxclient.so", "libtfhe_mi355x.so"):
+        line = [l for l in ldd.splitlines() if lib in l][0]
+        assert str(prefix) in line, line                     # not the build tree: the installed copy
+    assert subprocess.run([str(prefix / "client_preprocess"), "0"], cwd=tmp_path).returncode == 0
+    assert subprocess.run([str(prefix / "server_preprocess_dataset"), "2"], cwd=tmp_path).returncode == 0
+    r = subprocess.run([str(prefix / "server_encrypted_compute")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr
+    r = subprocess.run([str(prefix / "client_postprocess"), "7"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "size must be" in r.stderr

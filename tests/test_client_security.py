@@ -72,7 +72,27 @@ def test_encrypted_tables_decrypt_to_the_same_bits(keys256):
         assert np.array_equal(dec, (ref[idx][2] >> np.uint64(63)).astype(np.uint8))
 
 
-def test_unseeded_generator_without_entropy_is_an_error(keys256):
+@pytest.fixture(scope="module")
+def no_entropy_env(tmp_path_factory):
+    """LD_PRELOAD shim (test-only code, built here) that makes getrandom(2) and /dev/urandom fail: the product has
+    no switch that disables its entropy source"""
+    d = tmp_path_factory.mktemp("shim")
+    src = d / "noentropy.c"
+    src.write_text(
+        "#define _GNU_SOURCE\n#include <dlfcn.h>\n#include <errno.h>\n#include <stdio.h>\n#include <string.h>\n#include <sys/types.h>\n"
+        "ssize_t getrandom(void *b, size_t n, unsigned f) { (void)b; (void)n; (void)f; errno = ENOSYS; return -1; }\n"
+        "static FILE *deny(const char *p, const char *m, const char *sym) {\n"
+        "    if (p && !strcmp(p, \"/dev/urandom\")) { errno = ENOENT; return NULL; }\n"
+        "    FILE *(*real)(const char *, const char *) = (FILE *(*)(const char *, const char *))dlsym(RTLD_NEXT, sym);\n"
+        "    return real(p, m); }\n"
+        "FILE *fopen(const char *p, const char *m) { return deny(p, m, \"fopen\"); }\n"
+        "FILE *fopen64(const char *p, const char *m) { return deny(p, m, \"fopen64\"); }\n")
+    so = d / "noentropy.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", str(so), str(src), "-ldl"])
+    return dict(os.environ, LD_PRELOAD=str(so))
+
+
+def test_unseeded_generator_without_entropy_is_an_error(keys256, no_entropy_env):
     """seed == 0 is the production default of the client stages; no entropy must never mean a constant key"""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -82,8 +102,7 @@ def test_unseeded_generator_without_entropy_is_an_error(keys256):
         "except txclient.ClientError as e:\n"
         "    print('ERR', e); sys.exit(3)\n"
         "sys.exit(0)\n" % (os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"), ROOT))
-    env = dict(os.environ, TXC_TEST_NO_ENTROPY="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=no_entropy_env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "entropy" in r.stdout, (r.returncode, r.stdout, r.stderr)
     # and with entropy two unseeded generations differ
     import txhip, txclient
@@ -93,9 +112,9 @@ def test_unseeded_generator_without_entropy_is_an_error(keys256):
     assert not np.array_equal(a, b)
 
 
-def test_key_generation_stage_exits_nonzero_without_entropy(tmp_path):
+def test_key_generation_stage_exits_nonzero_without_entropy(tmp_path, no_entropy_env):
     exe = os.path.join(ROOT, "temp-fhe-transciphering_amd", "bin", "client_key_generation")
-    env = dict(os.environ, TXC_TEST_NO_ENTROPY="1")
+    env = dict(no_entropy_env)
     env.pop("TX_SEED", None)
     r = subprocess.run([exe, "0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "entropy" in r.stderr
@@ -114,7 +133,12 @@ def test_stage_reader_rejects_truncated_key_file(tmp_path):
     exe = os.path.join(ROOT, "temp-fhe-transciphering_amd", "bin", "server_encrypted_aes_decryption")
     r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1
-    assert "does not match the file size" in r.stderr or "HIP" in r.stderr or "tx_create" in r.stderr
+    assert "does not match the file size" in r.stderr          # the stage reads its key files before it touches the GPU
+    # well-formed files of the wrong length (keys of another parameter set) are refused the same way
+    for n in ("bsk", "ksk", "auto_keys", "ss_key"):
+        (d / (n + ".bin")).write_bytes(np.array([0x0000003436555854, 8], np.uint64).tobytes() + bytes(64))
+    r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "do not match the AES_TIGHT parameter set" in r.stderr
 
 
 def test_eval_key_word_counts_are_exported_and_consistent():

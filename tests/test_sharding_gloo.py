@@ -27,7 +27,7 @@ def test_shard_covers_every_block_once():
     assert txdist.iv_add(bytes(15) + b"\xff", 1) == bytes(14) + b"\x01\x00"
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, nb=3):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,8 +40,8 @@ def _worker(rank, world, port, mode, q):
     key, iv = bytes.fromhex(fx["aes_key"]), bytes.fromhex(fx["aes_iv"])
     p = O.aes_tight(n=256)
     keys = O.Keys(p, seed=33)                       # same seed on both ranks: identical key replicas
-    ctx = O.Ctx(keys, threads=4)
-    nb = 3                                          # ragged: rank 0 gets 2 blocks, rank 1 gets 1
+    ctx = O.Ctx(keys, threads=4 if world <= 2 else 1)
+    # nb = 3 on two ranks is ragged (2 + 1 blocks); nb = 5 on eight ranks leaves ranks 5..7 without a block
     pt = b"".join(int(v).to_bytes(2, "big") for v in fx["db"][: 8 * nb])
     if mode == "ctr":
         ct, luts, ivv = bytes.fromhex(fx["db_hex"])[: 16 * nb], keys.ctr_luts(key), iv
@@ -78,12 +78,14 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ctr"])
-def test_two_rank_sharded_transcipher_gloo(mode):
+@pytest.mark.parametrize("mode,world,nb", [("ctr", 2, 3), ("ctr", 8, 5)])
+def test_sharded_transcipher_and_max_gloo(mode, world, nb):
+    """world 2: ragged slabs; world 8 (the node size of BASELINE config 4): one block per rank and three ranks
+    without work -- the gather of the result LWEs and the gather of the partial maxima with empty ranks"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q, nb)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=600)
@@ -93,7 +95,7 @@ def test_two_rank_sharded_transcipher_gloo(mode):
     assert ok
 
 
-def _ip_worker(rank, world, port, q):
+def _ip_worker(rank, world, port, q, vals=(0x1234, 0xFFFF, 0x0003, 0x8001)):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -103,11 +105,12 @@ def _ip_worker(rank, world, port, q):
     import txdist
     p = O.aes_tight(n=256)
     keys = O.Keys(p, seed=33)
-    ctx = O.Ctx(keys, threads=4)
-    vals = [0x1234, 0xFFFF, 0x0003, 0x8001]                  # rank 0 holds values 0-1, rank 1 values 2-3
+    ctx = O.Ctx(keys, threads=4 if world <= 2 else 1)
+    vals = list(vals)                                        # contiguous ranges of len(vals) / world values per rank
+    per = len(vals) // world
     bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
     ct = torch.from_numpy(O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=8).view(np.int64))
-    ranges = [(0, 2), (2, 2)]
+    ranges = [(r * per, per) for r in range(world)]
     local = ct[ranges[rank][0] * 16:(ranges[rank][0] + ranges[rank][1]) * 16].clone()
 
     def local_ip(t):
@@ -116,7 +119,8 @@ def _ip_worker(rank, world, port, q):
     out = txdist.inner_product_sharded(local_ip, local, ranges, len(vals), rank, world, dist)
     if rank == 0:
         dec = O.lwe_decrypt_bits(keys.glwe_sk, out.numpy().view(np.uint64))
-        exp = sum((x * y) % 65536 for x, y in zip(vals[:2], vals[2:])) % 65536
+        half = len(vals) // 2
+        exp = sum((x * y) % 65536 for x, y in zip(vals[:half], vals[half:])) % 65536
         q.put(int("".join(str(int(b)) for b in dec), 2) == exp)
     else:
         assert out is None
@@ -124,13 +128,17 @@ def _ip_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_inner_product_gloo():
+@pytest.mark.parametrize("world,vals", [(2, (0x1234, 0xFFFF, 0x0003, 0x8001)),
+                                        (8, (0x1234, 0xFFFF, 0x0003, 0x8001, 0x7FFF, 0x0100, 0xABCD, 0x0001))])
+def test_sharded_inner_product_gloo(world, vals):
     """pairs dealt out over the ranks, one point-to-point exchange of the remote operands, partial sums
-    gathered and added by the same circuit on rank 0 (txdist.inner_product_sharded)"""
+    gathered and added by the same circuit on rank 0 (txdist.inner_product_sharded).  World 8 with eight values:
+    one value per rank, four pairs, so ranks 0..3 each hold one operand and fetch the other, and ranks 4..7
+    only send -- every branch of the exchange at the node size of BASELINE config 5."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 150)
-    procs = [ctx.Process(target=_ip_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29800 + (os.getpid() % 150) + world
+    procs = [ctx.Process(target=_ip_worker, args=(r, world, port, q, vals)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=600)
