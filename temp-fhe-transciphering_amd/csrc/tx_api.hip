@@ -130,16 +130,16 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     if (upload_tables(c) != 0) { tx_destroy(c); return nullptr; }
     // experiment knobs, parsed once and validated here (behind the stream and the tables, so that a bad value also
     // exercises the release of a half-built context)
-    if (env_knob("TX_BR_VARIANT", 0, 5, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
+    if (env_knob("TX_BR_VARIANT", 0, 6, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
         env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
         env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu)) { tx_destroy(c); return nullptr; }
     {
-        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5);
+        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6);
 #ifdef TXD_WITH_BR3
         ok = ok || c->br_variant == 3;
 #endif
         if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4)) {
-            fail("tx_create: TX_BR_VARIANT must be 0, 4 or 5 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
+            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5 or 6 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
             tx_destroy(c); return nullptr;
         }
     }
@@ -160,6 +160,8 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
 #endif
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate5), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR5) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate6), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR6) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); tx_destroy(c); return nullptr;
@@ -381,12 +383,23 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
     ev_begin(c, F_BR);
-    // Three kernels, same results bit for bit.  Above 4 units per CU every SIMD can hold two units: k_blind_rotate5 (generated
-    // assembly, two waves per SIMD in one persistent 512-thread workgroup per CU, fair arbitration between the two waves of a
-    // SIMD) runs; k_blind_rotate4 (the same loop in two independent 256-thread workgroups per CU) is 1 % behind it
-    // (TX_BR_VARIANT=4).  Below that a launch is one wave per SIMD anyway and k_blind_rotate (three transforms interleaved in
-    // 512 registers) is the faster one (1024 units: 8.0 against 8.5 ms; 8192 units: 59.7 against 46.6 ms).
-    const int variant = c->br_variant >= 0 ? c->br_variant : (count > (size_t)4 * c->num_cus ? 5 : 0);
+    // Same results bit for bit from every kernel; the choice is by launch size, in units per CU (measured on MI355X, n = 768):
+    //   > 4   every SIMD can hold two units: k_blind_rotate5 (generated assembly, two waves per SIMD in one persistent
+    //         512-thread workgroup per CU, fair arbitration between the two waves of a SIMD); k_blind_rotate4 (the same loop
+    //         in two independent 256-thread workgroups per CU) is 1 % behind it (TX_BR_VARIANT=4).
+    //   <= 3  the launch time is the length of ONE CMux chain: k_blind_rotate6 puts three waves on every unit, one per
+    //         polynomial (tx_br2.hpp): 128 units 2.95 against 7.2 ms, 512 units 4.7 against 7.2 ms, 768 units 6.4-7.0
+    //         against 7.5 ms.
+    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) four cooperative workgroups per CU load the
+    //         LDS store path and the vector pipes as fully as four one-wave units do and add two barriers per step: 7.9-8.5
+    //         against 7.5-8.2 ms for k_blind_rotate (one wave per unit, hipcc; TX_BR_VARIANT=0), which therefore runs here.
+    const int variant = c->br_variant >= 0 ? c->br_variant
+                        : (count > (size_t)4 * c->num_cus ? 5 : (count <= (size_t)3 * c->num_cus ? 6 : 0));
+    if (variant == 6) {
+        c->last_br_kernel = "k_blind_rotate6";
+        hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count,
+                           (int)c->p.n, c->bsk_f, c->tw);
+    } else
     if (variant == 5) {
         size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
         if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only

@@ -425,6 +425,81 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 }
 
 // ------------------------------------------------------------------------------------------
+// k_blind_rotate6: the COOPERATIVE blind rotation for launches of at most one unit per SIMD (the 8-blocks-per-GPU share
+// of the medium instance on an 8-GPU node: 1024 units on 256 CUs; a single AES block: 128 units).  A CMux chain is 768
+// dependent steps, so with one unit per SIMD the step time is the launch time, and no schedule of ONE wave shortens it
+// (a generated one-wave loop measured equal to k_blind_rotate).  Here a workgroup of THREE waves works on one unit, wave
+// c owning polynomial c of the accumulator for the whole chain: it rotates and decomposes its polynomial, transforms the
+// digits, publishes the transform through its transpose tile (idle at that point), multiply-accumulates column c
+// against the three published transforms, inverts and updates its polynomial -- one transform each way per wave and
+// step instead of three, the accumulator never moves, 8 KiB per wave and step cross through LDS, two s_barrier per
+// step.  The loop is generated (tools/asmgen/brgen3.py -> tx_br3_asm.inc, 168 registers: three waves per SIMD when the
+// launch fills the chip, four workgroups of 34 048 B LDS per CU); same products in the same order: bit-identical to
+// k_blind_rotate and the oracle.
+// ------------------------------------------------------------------------------------------
+constexpr int BR6_WAVES = 3;
+constexpr size_t LDS_BYTES_BR6 = BR3_TW_CPLX * sizeof(cplx) + BR6_WAVES * BR3_TILE_BYTES;
+static_assert(4 * LDS_BYTES_BR6 <= 160 * 1024, "four workgroups per CU");
+
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int unit = (int)blockIdx.x;                   // the grid is `count` workgroups
+    if (unit >= count) return;                          // (uniform per workgroup: no wave is left alone at a barrier)
+    unsigned char *tile0 = lds + BR3_TW_CPLX * sizeof(cplx);
+    unsigned char *tile = tile0 + (size_t)wave * BR3_TILE_BYTES;
+    uint64_t *pl = reinterpret_cast<uint64_t *>(tile);
+    const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+    if (wave == KP - 1) {   // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101: the body polynomial belongs to the last wave
+        const int rot = 2 * N - (int)modswitch(ct[n]);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int src = lane + 64 * m - rot;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            pl[lane + 64 * m] = (x ^ neg) - neg;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) pl[lane + 64 * m] = 0;
+    }
+    __syncthreads();
+    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
+    const uint32_t tile0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile0);
+    const cplx *col = bsk_f + (size_t)wave * H;                         // key[q][c] of row i: col + (i * 9 + q * 3) * H
+    uint64_t *out = acc_out + (size_t)unit * GL + (size_t)wave * N;
+#ifdef TXD_STAMPS_BR6   // diagnostic build: per-phase cycle sums of wave TXD_STAMP_THREAD / 64 of workgroup TXD_STAMP_BLOCK
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == (TXD_STAMP_THREAD / 64) % 3) ? txd_stamps : txd_stamps_sink;
+    if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const int rt_slot = (wave == 0 && unit < 4096) ? unit : -1;
+    asm volatile(
+#include "tx_br3_asm_stamps.inc"
+        :
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(dbg)
+        :
+#include "tx_br3_asm_clobbers.inc"
+    );
+    if (rt_slot >= 0 && (threadIdx.x & 63) == 0) { txd_wave_rt[2 * rt_slot] = rt0; txd_wave_rt[2 * rt_slot + 1] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    asm volatile(
+#include "tx_br3_asm.inc"
+        :
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr)
+        :
+#include "tx_br3_asm_clobbers.inc"
+    );
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // k_extract_trace4: k_extract_trace with trace_lds() replaced by the generated loop of tools/asmgen/trgen.py
 // (tx_trace_asm.inc): one wave per SIMD as before, but the six digit transforms of a step are parked in accumulation
 // registers, which leaves room for two key register sets (the LDS read of the next key polynomial is in flight

@@ -1,0 +1,112 @@
+"""Runs the generated COOPERATIVE blind-rotation loop (tools/asmgen/brgen3.py: three waves per unit, wave c owns
+polynomial c) as a workgroup of three emulated waves -- one shared LDS image, every s_barrier honoured -- against the
+same reference as tests/asmgen_emu_blind_rotate.py (the CPU oracle's primitives).  The waves are scheduled between
+barriers first in the order 0, 1, 2 and then 2, 1, 0: a missing barrier around the published transforms shows as a
+mismatch in one of the two.  Must match bit for bit; a register read before its load was waited for raises.
+
+    python3 tests/asmgen_emu_blind_rotate3.py [steps=2] [seed=1]
+"""
+import ctypes as C
+import os
+import sys
+import time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen"))
+sys.path.insert(0, HERE)
+import gcn
+import brgen
+import brgen3
+import asmgen_emu_blind_rotate as one
+
+N, H, KP = one.N, one.H, one.KP
+TW_BYTES = one.TW_BYTES
+TILE_BYTES = 8320
+LDS_BYTES = TW_BYTES + 3 * TILE_BYTES
+
+
+def run_group_ordered(emus, prog, order):
+    gens = [e.run_gen(prog) for e in emus]
+    alive = [True] * len(gens)
+    while any(alive):
+        states = []
+        for k in order:
+            if not alive[k]: continue
+            try:
+                states.append(next(gens[k]))
+            except StopIteration:
+                alive[k] = False
+                states.append("end")
+        if len(set(states)) != 1: raise RuntimeError("waves disagree at a barrier: %s" % states)
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    L = one.oracle()
+    H_ = gcn._helpers()
+    p = one.p
+    tw = np.ctypeslib.as_array(L.txo_twiddles_1024(), shape=(15, 64, 2)).copy().view(np.complex128).reshape(15, 64)
+    key = np.zeros((steps, KP, KP, H), np.complex128)
+    L.txo_fft_forward_torus_scaled.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    for i in range(steps):
+        for q in range(KP):
+            for c in range(KP):
+                pol = rng.integers(0, 1 << 63, N, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, N, dtype=np.uint64)
+                out = np.zeros(N, np.float64)
+                L.txo_fft_forward_torus_scaled(N, p(pol, C.c_uint64), p(out, C.c_double))
+                key[i, q, c] = out.view(np.complex128)
+    lwe = rng.integers(0, 1 << 63, steps + 1, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, steps + 1, dtype=np.uint64)
+    if steps >= 2: lwe[1] = 0                                        # a zero mask element: rotation by 0
+    ref = one.reference(L, H_, lwe, key, steps)
+    rot0 = 2 * N - int(L.txo_modswitch(C.c_uint64(int(lwe[-1])), 10, 3))
+    tv = np.zeros(N, np.uint64)
+    for i in range(N):
+        v = np.uint64(1) << np.uint64(63 - 2 * ((i & 7) + 1))
+        tv[i] = (np.uint64(0) - v) if i < N // 2 else v
+    prog = brgen3.CoopGen(stamps=bool(os.environ.get("BR_STAMPS"))).build()
+    ok = True
+    for order in ([0, 1, 2], [2, 1, 0]):
+        lds = np.zeros(LDS_BYTES, np.uint8)
+        lw = lds.view(np.complex128)
+        lw[:8 * 64] = tw[:8].reshape(-1)
+        for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
+        # what the kernel's HIP part leaves in the tiles: zero mask polynomials, the rotated test vector as the body
+        lds[TW_BYTES + 2 * TILE_BYTES: TW_BYTES + 2 * TILE_BYTES + 8192].view(np.uint64)[:] = one.rotate(tv, rot0)
+        CT, ROW, OUT = 0x1000_0000, 0x2000_0000, 0x3000_0000
+        ct_buf = lwe.copy().view(np.uint8)
+        key_buf = key.reshape(-1).view(np.uint8).copy()
+        out_buf = np.zeros(KP * N * 8, np.uint8)
+        SG = brgen.SG
+        emus = []
+        for c in range(3):
+            e = gcn.Emu(lds, [(CT, ct_buf), (ROW, key_buf), (OUT, out_buf)])
+            for s, val in ((SG.CT, CT), (SG.ROW, ROW + c * H * 16), (SG.OUT, OUT + c * N * 8)):
+                e.s[s.i] = val & 0xFFFFFFFF; e.s[s.i + 1] = val >> 32
+            e.s[SG.NSTEP.i] = steps
+            e.s[SG.TILE.i] = TW_BYTES + c * TILE_BYTES
+            e.s[brgen3.TILE0.i] = TW_BYTES
+            if os.environ.get("BR_STAMPS"):
+                dbg = np.zeros(128, np.uint8); e.g.append((0x4000_0000 + 0x1000 * c, dbg))
+                e.s[brgen.ST_DBG.i] = 0x4000_0000 + 0x1000 * c; e.s[brgen.ST_DBG.i + 1] = 0
+            emus.append(e)
+        t = time.time()
+        run_group_ordered(emus, prog, order)
+        got = out_buf.view(np.uint64).reshape(KP, N)
+        same = np.array_equal(got, ref)
+        ok = ok and same
+        top = max(max((x.i + x.n) for x in i.a if isinstance(x, gcn.V)) for i in prog.ins if any(isinstance(x, gcn.V) for x in i.a))
+        print("steps %d seed %d order %s: %d instructions per wave, top VGPR %d, %.1f s -> %s" %
+              (steps, seed, order, emus[0].nexec, top, time.time() - t, "BIT-IDENTICAL" if same else "MISMATCH"))
+        if not same:
+            for q in range(KP):
+                bad = np.nonzero(got[q] != ref[q])[0]
+                print("  poly %d: %d mismatches" % (q, bad.size), bad[:8], [hex(int(x)) for x in got[q][bad[:3]]], [hex(int(x)) for x in ref[q][bad[:3]]])
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,19 @@ def test_fair_variant_is_the_same_arithmetic_on_both_priority_paths(oracle):
         assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_cooperative_loop_equals_oracle_three_waves(oracle):
+    """tools/asmgen/brgen3.py (k_blind_rotate6: three waves per unit, one per polynomial): a workgroup of three emulated
+    waves sharing the LDS image and meeting at both barriers of every step, scheduled in both orders between barriers,
+    against the same oracle-built reference as the one-wave loops; the stamped variant is the same arithmetic; without
+    the barriers (timing ablation) the emulation must NOT match -- the test can see a missing barrier"""
+    exe = os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate3.py")
+    for steps, seed, env in ((3, 1, {}), (2, 77, {}), (2, 5, {"BR_STAMPS": "1"})):
+        r = subprocess.run([sys.executable, exe, str(steps), str(seed)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, exe, "2", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR3_ABL="B"))
+    assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
+
+
 def test_stamped_variant_is_the_same_arithmetic(oracle):
     env = dict(os.environ, BR_STAMPS="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
@@ -56,9 +69,10 @@ def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "trgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "fftconst.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "ssgen.py"), "--out", str(tmp_path)])
+    subprocess.check_call([sys.executable, os.path.join(GEN, "brgen3.py"), "--out", str(tmp_path)])
     # (the *_stamps.inc diagnostic variants the generators also write are build-time output, not tracked)
     for f in ("tx_fft_consts.inc", "tx_ss_asm.inc", "tx_br_asm.inc", "tx_br_asm_fair.inc", "tx_br_asm_clobbers.inc",
-              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc"):
+              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 
@@ -107,22 +121,24 @@ def test_scratch_of_the_built_kernels():
         hits = [v for n, v in k.items() if stem in n]
         assert len(hits) == 1, (stem, sorted(k))
         return hits[0]
-    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate4"):
+    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate4", "15k_blind_rotate6"):
         assert find(stem)["private_segment_fixed_size"] == 0, stem
     assert find("15k_blind_rotate5")["private_segment_fixed_size"] <= 128
     assert find("15k_blind_rotate5")["vgpr_count"] == 256 and find("15k_blind_rotate4")["vgpr_count"] == 256
+    assert find("15k_blind_rotate6")["vgpr_count"] == 168            # three waves per SIMD
 
 
 def test_register_budget_and_no_scratch():
     """the generated loops fit 256 VGPRs and issue no scratch instruction (what hipcc keeps around them is bounded by
     test_scratch_of_the_built_kernels): two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, trgen, ssgen, gcn
-    for prog in (brgen.Gen().build(), trgen.TraceGen().build(), ssgen.SsGen().build()):
+    import brgen, brgen3, trgen, ssgen, gcn
+    for prog, budget in ((brgen.Gen().build(), 256), (trgen.TraceGen().build(), 256), (ssgen.SsGen().build(), 256),
+                         (brgen3.CoopGen().build(), 168)):
         top = 0
         for i in prog.ins:
             for x in i.a:
                 if isinstance(x, gcn.V): top = max(top, x.i + x.n)
                 if isinstance(x, gcn.S) and x.i != 124: assert x.i + x.n <= 96, "the top six SGPRs are VCC / flat scratch / xnack"
-        assert top <= 256
+        assert top <= budget
         assert not any(i.op.startswith("scratch_") for i in prog.ins)

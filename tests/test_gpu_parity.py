@@ -268,7 +268,7 @@ def test_medium_instance_ecb_schedule_decrypts_exactly(rig768):
     out = r.eng.transcipher(ct)
     assert O.bits_msb_to_bytes(O.lwe_decrypt_bits(r.keys.glwe_sk, out)) == pt
     alone = r.eng.transcipher(ct[16 * 37:16 * 38])
-    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate"               # 128 units: the small-launch kernel
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate6"              # 128 units: the small-launch kernel
     assert np.array_equal(alone, out[128 * 37:128 * 38])
     assert np.array_equal(r.eng.transcipher(ct[:48]), out[:128 * 3])          # ragged batch of 3
 
@@ -433,7 +433,7 @@ def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
 def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     """BASELINE config 4's per-GPU share on one card: 31 blocks over FOUR ranks (gloo; a GPU box admits at most six
     processes on its card, so the node's eight ranks cannot be rehearsed here) = 8 + 8 + 8 + 7 blocks, i.e. launches
-    of 1024 units -- one per SIMD, the small-launch blind rotation -- a ragged gather, the gather of four partial
+    of 1024 and 896 units -- one per SIMD: k_blind_rotate (rank 0) and the cooperative k_blind_rotate6 (rank 3) -- a ragged gather, the gather of four partial
     maxima and the inner product's point-to-point step with 124 pairs dealt over four ranks"""
     import subprocess
     import sys as _sys
@@ -487,11 +487,12 @@ def test_trace_and_scheme_switch_ring_stress(rig256):
     assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
 
 
-@pytest.mark.parametrize("variant", ["4", "5"])
+@pytest.mark.parametrize("variant", ["0", "4", "5", "6"])
 @pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
-def test_two_wave_blind_rotation_kernel_bit_identical(which, variant, request, monkeypatch):
-    """k_blind_rotate4 / k_blind_rotate5 (generated assembly, csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair
-    arbitration) forced on a small launch: equals the oracle"""
+def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monkeypatch):
+    """k_blind_rotate (hipcc, one wave per unit), k_blind_rotate4 / k_blind_rotate5 (generated assembly, two waves per SIMD,
+    csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair arbitration) and k_blind_rotate6 (generated, three waves per
+    unit, csrc/tx_br3_asm.inc), each forced on a small ragged launch: equals the oracle"""
     import txhip
     r = request.getfixturevalue(which)
     rng = np.random.default_rng(17)
@@ -504,8 +505,37 @@ def test_two_wave_blind_rotation_kernel_bit_identical(which, variant, request, m
     e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)      # 13 units: a ragged last workgroup
     e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     got = e4.blind_rotate(lwe)
+    assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6"}[variant]
+    one = e4.blind_rotate(lwe[5:6])                     # a single unit
     e4.close()
     assert np.array_equal(got, ref)
+    assert np.array_equal(one, ref[5:6])
+
+
+def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
+    """k_blind_rotate6 with the chip full of it -- 1024 units at n = 768 (four workgroups of three waves on every CU,
+    twelve waves per CU meeting at two barriers per step; forced: the dispatch gives launches above three units per CU
+    to the one-wave kernel) and 768 units as the dispatch itself picks it: same bits as the one-wave kernel on every
+    unit, twice (a race would not repeat), and the oracle's on a sample"""
+    import txhip
+    r = rig768
+    rng = np.random.default_rng(37)
+    cnt = 1024
+    lwe = rng.integers(0, 1 << 63, (cnt, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.p.n + 1), dtype=np.uint64)
+    one_wave = r.eng.blind_rotate(lwe)
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate"
+    monkeypatch.setenv("TX_BR_VARIANT", "6")
+    e6 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e6.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    coop = e6.blind_rotate(lwe)
+    assert e6.last_blind_rotate_kernel() == "k_blind_rotate6"
+    assert np.array_equal(e6.blind_rotate(lwe), one_wave)
+    e6.close()
+    assert np.array_equal(coop, one_wave)
+    assert np.array_equal(r.eng.blind_rotate(lwe[:768]), one_wave[:768])
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate6"
+    pick = np.r_[0:3, cnt - 3:cnt]
+    assert np.array_equal(coop[pick], r.octx.blind_rotate(lwe[pick]))
 
 
 def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):

@@ -24,7 +24,8 @@ if hasattr(txhip.lib(), "tx_debug_stamps"):        # -DTXD_STAMPS build: cycles 
     txhip.lib().tx_debug_stamps(C.c_void_p(eng.h), st)
     names = ["rotate+decompose", "forward x3", "MAC", "inverse x3", "convert+update"]
     steps = max(1, st[6])
-    print("stamps (cycles/step):", {n: round(st[i] / steps) for i, n in enumerate(names)}, "sum", round(sum(st[:5]) / steps))
+    print("stamps (cycles/step):", {n: round(st[i] / steps) for i, n in enumerate(names)}, "sum", round(sum(st[:5]) / steps),
+          "| waiting at barriers (k_blind_rotate6):", round(st[5] / steps))
     print("raw stamps 8..11:", [int(st[k]) for k in range(8, 12)])
     if st[10] > st[8] and st[11] > st[9]:      # generated loop: s_memtime / s_memrealtime (100 MHz) at the start and the end of the unit
         print("shader clock of that wave: %.3f GHz over %.2f ms" % ((st[10] - st[8]) / (st[11] - st[9]) * 0.1, (st[11] - st[9]) * 1e-5))
@@ -34,8 +35,8 @@ if len(sys.argv) > 4:
     for r in range(reps):
         eng.extract_trace(acc)
         print("extract_trace", acc.shape[0] * 7, "units:", round(eng.timing()["ms_trace"], 3), "ms", flush=True)
-if hasattr(txhip.lib(), "tx_debug_wave_times") and os.environ.get("TX_BR_VARIANT", "4") == "4":
-    nw = min(4096, count // 4)
+if hasattr(txhip.lib(), "tx_debug_wave_times") and os.environ.get("TX_BR_VARIANT", "4") in ("4", "6"):
+    nw = min(4096, count // 4 if os.environ.get("TX_BR_VARIANT", "4") == "4" else count)
     buf = (C.c_ulonglong * (2 * nw))()
     txhip.lib().tx_debug_wave_times(C.c_void_p(eng.h), buf, 2 * nw)
     a = np.array(buf[:], np.uint64).reshape(-1, 2).astype(np.int64)
