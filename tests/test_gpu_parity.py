@@ -433,7 +433,7 @@ def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
 def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     """BASELINE config 4's per-GPU share on one card: 31 blocks over FOUR ranks (gloo; a GPU box admits at most six
     processes on its card, so the node's eight ranks cannot be rehearsed here) = 8 + 8 + 8 + 7 blocks, i.e. launches
-    of 1024 and 896 units -- one per SIMD: k_blind_rotate (rank 0) and the cooperative k_blind_rotate6 (rank 3) -- a ragged gather, the gather of four partial
+    of 1024 and 896 units -- above three units per CU: the one-wave k_blind_rotate, as run_br dispatches -- a ragged gather, the gather of four partial
     maxima and the inner product's point-to-point step with 124 pairs dealt over four ranks"""
     import subprocess
     import sys as _sys
