@@ -26,6 +26,11 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 la
 # Infinity Cache.  k_blind_rotate5 (two waves per SIMD, persistent; runs above 4 units per CU):
 # profiles/r2_final_pmc_{fetch,write}_size_blind_rotate5.csv (each XCD streams the key 4 times, once per unit of a wave);
 # k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
+# The default command (medium, CTR, shared columns): its nine k_blind_rotate5 launches per step are eight of 8192 units and
+# one of 2048 (the second round's distinct columns; the 96 units of its ragged tail go to k_blind_rotate6).  Average per
+# launch over exactly those launches, separate --pmc passes over `bench.py --steps 1` (tools/profile_round.sh):
+# profiles/r3g_pmc_{fetch,write}_size_bench_command.csv: FETCH_SIZE 852 378 KiB (x 2), WRITE_SIZE 191 488 KiB.
+BR_TRAFFIC_AVG_DEFAULT_MIX = (852378 * 2 + 191488) * 1024
 BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930104 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
                          "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
 # PMC pass over the same launch (tools/pmc_kernel.sh, profiles/r2c_pmc_sq_blind_rotate5.csv): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
@@ -41,9 +46,9 @@ def algorithmic_bytes_per_block(M):
     return 1.847e9 + 0.556e9 / M
 
 
-def br_launch_bytes(M, n):
-    """blind-rotation launch: per bit in (n+1) words + out 3*1024 words; BSK (standard size) once"""
-    return M * 128 * ((n + 1) * 8 + 3 * 1024 * 8) + n * 9 * 1024 * 8
+def br_launch_bytes(units, n, launches=1):
+    """blind-rotation launches: per unit (bit) in (n+1) words + out 3*1024 words; BSK (standard size) once per launch"""
+    return units * ((n + 1) * 8 + 3 * 1024 * 8) + launches * n * 9 * 1024 * 8
 
 
 def cpu_baseline(n, seed, threads):
@@ -90,10 +95,15 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --blocks in total (the medium instance); weak: --blocks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ctr-share", action="store_true",
+                    help="CTR mode: bootstrap every state column of the second round, also those that hold the same ciphertexts "
+                         "in every block of the batch (TX_CTR_SHARE=0; same results, for A/B timing)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
+    if args.no_ctr_share:
+        os.environ["TX_CTR_SHARE"] = "0"             # read once by tx_create
     import numpy as np
     import torch
     import __graft_entry__
@@ -147,14 +157,15 @@ def main():
     t_load = time.time() - t0
 
     words = 2 * 1024 + 1
-    br_ms, br_launches = [0.0], [0]
+    br_ms, br_launches, br_units = [0.0], [0], [0]
 
     def local_fn(ct_slab, iv_slab, n_local, n_pad):
         out = torch.empty((n_pad * 128, words), dtype=torch.int64, device=dev)
         if n_local:
             eng.transcipher(ct_slab, iv_slab, out_device_ptr=out.data_ptr())
             tm = eng.timing()
-            br_ms[0] += tm["ms_blind_rotate"]; br_launches[0] += tm["n_blind_rotate"]
+            # the blind-rotation kernel that took most units (a call may split a ragged tail off to a small-launch kernel)
+            br_ms[0] += tm["ms_br_main"]; br_launches[0] += tm["n_br_main"]; br_units[0] += tm["units_br_main"]
         return out
 
     def step():
@@ -175,7 +186,7 @@ def main():
     del res
     for _ in range(max(0, args.warmup - 1)):
         step()
-    br_ms[0], br_launches[0] = 0.0, 0
+    br_ms[0], br_launches[0], br_units[0] = 0.0, 0, 0
     last_timing = None
     barrier()
     t0 = time.perf_counter()
@@ -193,8 +204,13 @@ def main():
         _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
         br_avg_ms = br_ms[0] / max(1, br_launches[0])
+        br_avg_units = br_units[0] / max(1, br_launches[0])
         br_kernel = eng.last_blind_rotate_kernel()         # what run_br (csrc/tx_api.hip) launched, as the library reports it
-        achieved = br_launch_bytes(m_local, args.n) / (br_avg_ms * 1e-3) / 1e9
+        # all launches of that kernel in the timed region (they differ in size: in CTR mode the second round bootstraps
+        # only the distinct state columns): algorithmic bytes of all of them over the time of all of them
+        achieved = br_launch_bytes(br_units[0], args.n, br_launches[0]) / (br_ms[0] * 1e-3) / 1e9
+        br_flops = br_units[0] * args.n * BR_F64_FLOP_PER_UNIT_STEP
+        default_mix = (m_local == 64 and args.n == 768 and args.mode == "ctr" and not args.no_ctr_share and br_kernel == "k_blind_rotate5")
         line = {
             "metric": "AES blocks transciphered/sec (medium instance)", "value": value, "unit": "AES blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -205,14 +221,14 @@ def main():
                        "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather"},
             "roofline": {"bound": "hbm", "kernel": br_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (BR_TRAFFIC_BYTES_8192.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
-                         "avg_launch_ms": br_avg_ms, "launches": br_launches[0],
-                         "algorithmic_bytes_per_launch": br_launch_bytes(m_local, args.n),
+                         "traffic": (BR_TRAFFIC_AVG_DEFAULT_MIX if default_mix else
+                                     (BR_TRAFFIC_BYTES_8192.get(br_kernel) if abs(br_avg_units - 8192) < 0.5 and args.n == 768 else None)),
+                         "avg_launch_ms": br_avg_ms, "launches": br_launches[0], "avg_units_per_launch": br_avg_units,
+                         "algorithmic_bytes_per_launch": br_launch_bytes(br_units[0], args.n, br_launches[0]) / max(1, br_launches[0]),
                          "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,
                          "path_frac": value / world * algorithmic_bytes_per_block(m_local) / 1e9 / HBM_PEAK_GBS,
-                         "fp64_valu": {"achieved_TFLOPs": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12,
-                                       "peak_TFLOPs": FP64_PEAK_TFLOPS,
-                                       "frac": m_local * 128 * args.n * BR_F64_FLOP_PER_UNIT_STEP / (br_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "fp64_valu": {"achieved_TFLOPs": br_flops / (br_ms[0] * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                                       "frac": br_flops / (br_ms[0] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                          "vector_pipe_busy_pmc": (BR_VALU_BUSY_PMC.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
                          "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
                                  "fp64_valu counts FP64 flops against the FMA peak at the nominal clock (half of this loop's FP64 "
@@ -220,6 +236,12 @@ def main():
                                  "1.85-1.9 GHz: power-bound); vector_pipe_busy_pmc is the fraction of cycles a SIMD's vector pipe "
                                  "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES, "
                                  "profiles/r2c_pmc_sq_blind_rotate5.csv)"},
+            "ctr_shared_columns": (None if args.mode != "ctr" else
+                                   {"enabled": not args.no_ctr_share,
+                                    "note": "CTR: the state entering the second round is a public function of the counters, so columns fed by "
+                                            "the same counter bytes hold the same ciphertexts in every block; each distinct column is "
+                                            "bootstrapped once (64 consecutive counters: 268 of 1024 bytes in that round, the other 8 "
+                                            "rounds in full); outputs identical to evaluating every column (--no-ctr-share does)"}),
             "kernel_ms_last_step": {k: round(v, 3) for k, v in last_timing.items() if k.startswith("ms_")},
             "setup_s": {"client_keygen": round(t_keygen, 2), "key_upload_and_transform": round(t_load, 3)},
         }

@@ -47,7 +47,8 @@ const char *tx_last_error(void);
 /* Replaces the key-conversion prologue of `main` (server_encrypted_aes_decryption.rs:640-687):
  * creates a context on HIP device `device`. */
 /* Experiment knobs (environment, read and validated ONCE here; an ill-formed or out-of-range value makes tx_create
- * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU.  Unset = the product path. */
+ * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU, TX_CTR_SHARE.  Unset = the
+ * product path. */
 tx_ctx *tx_create(const tx_params *p, int device);
 void    tx_destroy(tx_ctx *c);
 
@@ -78,7 +79,9 @@ int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words);
 
 /* Replaces `aes_to_lwe_trasnciphering` (server_encrypted_aes_decryption.rs:28-191), batched over
  * n_blocks independent 16-byte AES blocks.  iv == NULL: the reference's ECB inverse-cipher
- * schedule; iv != NULL: CTR mode on counter blocks iv + i.  out_lwe: n_blocks*128 LWE
+ * schedule; iv != NULL: CTR mode on counter blocks iv + i (the second round of a CTR batch bootstraps every DISTINCT
+ * state column once: the counters of a batch agree in all but their last bytes, so most columns of that round hold the
+ * same ciphertexts in every block; same results as evaluating each, TX_CTR_SHARE=0 does).  out_lwe: n_blocks*128 LWE
  * ciphertexts of kN+1 words, bit order MSB first inside each byte (:182-189).
  * out_is_device != 0: out_lwe is a device pointer on the context's GPU (result stays in HBM). */
 int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
@@ -126,11 +129,16 @@ int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes, int ctr, i
 typedef struct {
     double ms_keyswitch, ms_blind_rotate, ms_trace, ms_scheme_switch, ms_lut_eval, ms_linear, ms_total;
     uint32_t n_keyswitch, n_blind_rotate, n_trace, n_scheme_switch, n_lut_eval, n_linear;
+    /* the blind-rotation kernel that processed most units of the call (tx_last_blind_rotate_kernel names it): its time,
+     * launches and units -- a call may use more than one kernel (dispatch by launch size, split tails) */
+    uint32_t n_br_main;
+    double ms_br_main;
+    uint64_t units_br_main;
 } tx_timing;
 int tx_get_timing(tx_ctx *c, tx_timing *t);
-/* name of the blind-rotation kernel the last launch used ("k_blind_rotate5", "k_blind_rotate", ...; "" before the
- * first launch).  The dispatch is by launch size (and the TX_BR_VARIANT experiment knob, read once by tx_create):
- * the measurement reports what ran, not what a copy of the rule predicts. */
+/* name of the blind-rotation kernel that processed most units of the last call ("k_blind_rotate5", "k_blind_rotate6",
+ * "k_blind_rotate", ...; "" before the first call).  The dispatch is by launch size (and the TX_BR_VARIANT experiment
+ * knob, read once by tx_create): the measurement reports what ran, not what a copy of the rule predicts. */
 const char *tx_last_blind_rotate_kernel(const tx_ctx *c);
 
 /* the forward-transform twiddle table [15][64] complex used by the kernels (for table pinning): eight pass-A rows

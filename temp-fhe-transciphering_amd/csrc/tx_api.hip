@@ -42,7 +42,10 @@ struct tx_ctx {
     int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4|5 forces a kernel
     int br5_wgs = 0;                        // 0: one workgroup per CU; TX_BR5_WGS caps the persistent grid (experiments)
     int trss_wgs_per_cu = 1;                // TX_TRSS_WGS_PER_CU (experiments)
-    const char *last_br_kernel = "";        // what run_br launched last (tx_last_blind_rotate_kernel)
+    int ctr_share = 1;                      // TX_CTR_SHARE=0: the CTR schedule bootstraps every column of its second round, shared or not
+    const char *last_br_kernel = "";        // blind-rotation kernel that took most units of the last call (tx_last_blind_rotate_kernel)
+    uint64_t *share_tmp = nullptr; size_t share_tmp_bits = 0;      // compact LUT output of the CTR schedule's shared round
+    int *d_idx = nullptr; uint8_t *d_pos = nullptr; size_t idx_cap = 0;
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
     bool have_keys = false;
     // workspace (grown on demand)
@@ -51,7 +54,8 @@ struct tx_ctx {
     cplx *ggsw_f = nullptr;
     uint8_t *d_bytes = nullptr, *d_ct = nullptr;
     // timing
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
+    struct Ev { int fam; const char *kernel; size_t units; hipEvent_t a, b; };
+    std::vector<Ev> evs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     tx_timing timing;
@@ -132,7 +136,7 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     // exercises the release of a half-built context)
     if (env_knob("TX_BR_VARIANT", 0, 6, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
         env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
-        env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu)) { tx_destroy(c); return nullptr; }
+        env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu) || env_knob("TX_CTR_SHARE", 0, 1, c->ctr_share)) { tx_destroy(c); return nullptr; }
     {
         bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6);
 #ifdef TXD_WITH_BR3
@@ -183,6 +187,8 @@ static void free_ws(tx_ctx *c)
     hipFree(c->st); hipFree(c->sm); hipFree(c->small); hipFree(c->acc); hipFree(c->glev); hipFree(c->res);
     hipFree(c->ggsw_f); hipFree(c->d_bytes); hipFree(c->d_ct);
     c->st = c->sm = c->small = c->acc = c->glev = c->res = nullptr; c->ggsw_f = nullptr; c->d_bytes = c->d_ct = nullptr;
+    hipFree(c->share_tmp); hipFree(c->d_idx); hipFree(c->d_pos);
+    c->share_tmp = nullptr; c->d_idx = nullptr; c->d_pos = nullptr; c->share_tmp_bits = 0; c->idx_cap = 0;
     c->ws_blocks = 0; c->glev_bits = 0;
 }
 
@@ -210,7 +216,7 @@ static size_t ctr_lut_words() { return (size_t)10 * 3 * 16 * 2 * GL; }
 static inline int grid_for(size_t units) { return (int)((units + WAVES - 1) / WAVES); }
 
 // ---- timing helpers: HIP events on the launch stream ----
-static void ev_begin(tx_ctx *c, int fam)
+static void ev_begin(tx_ctx *c, int fam, const char *kernel = "", size_t units = 0)
 {
     if (!c->time_enabled) return;
     if (c->ev_used == c->ev_pool.size()) {
@@ -219,7 +225,7 @@ static void ev_begin(tx_ctx *c, int fam)
     }
     auto &e = c->ev_pool[c->ev_used];
     hipEventRecord(e.first, c->stream);
-    c->evs.push_back({fam, e});
+    c->evs.push_back({fam, kernel, units, e.first, e.second});
 }
 static void ev_end(tx_ctx *c)
 {
@@ -231,9 +237,18 @@ static void timing_reset(tx_ctx *c) { c->evs.clear(); c->ev_used = 0; memset(&c-
 static void timing_collect(tx_ctx *c)
 {
     double ms[F_COUNT] = {0}; uint32_t cnt[F_COUNT] = {0};
+    // the blind rotation by kernel: a call may use more than one (launch-size dispatch, split tails)
+    struct G { const char *k; double ms; uint32_t n; uint64_t units; };
+    std::vector<G> br;
     for (auto &e : c->evs) {
-        float t = 0; hipEventElapsedTime(&t, e.second.first, e.second.second);
-        ms[e.first] += t; cnt[e.first]++;
+        float t = 0; hipEventElapsedTime(&t, e.a, e.b);
+        ms[e.fam] += t; cnt[e.fam]++;
+        if (e.fam == F_BR) {
+            size_t g = 0;
+            while (g < br.size() && strcmp(br[g].k, e.kernel) != 0) g++;
+            if (g == br.size()) br.push_back({e.kernel, 0.0, 0, 0});
+            br[g].ms += t; br[g].n++; br[g].units += e.units;
+        }
     }
     tx_timing &t = c->timing;
     t.ms_keyswitch = ms[F_KS]; t.ms_blind_rotate = ms[F_BR]; t.ms_trace = ms[F_TRACE];
@@ -241,6 +256,9 @@ static void timing_collect(tx_ctx *c)
     t.n_keyswitch = cnt[F_KS]; t.n_blind_rotate = cnt[F_BR]; t.n_trace = cnt[F_TRACE];
     t.n_scheme_switch = cnt[F_SS]; t.n_lut_eval = cnt[F_LUT]; t.n_linear = cnt[F_LIN];
     t.ms_total = 0; for (int i = 0; i < F_COUNT; i++) t.ms_total += ms[i];
+    t.ms_br_main = 0; t.n_br_main = 0; t.units_br_main = 0;
+    for (auto &g : br)
+        if (g.units > t.units_br_main) { t.units_br_main = g.units; t.ms_br_main = g.ms; t.n_br_main = g.n; c->last_br_kernel = g.k; }
 }
 extern "C" int tx_get_timing(tx_ctx *c, tx_timing *t) { if (!c || !t) return fail("tx_get_timing: null"); *t = c->timing; return 0; }
 extern "C" const char *tx_last_blind_rotate_kernel(const tx_ctx *c) { return c ? c->last_br_kernel : ""; }
@@ -380,9 +398,33 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
                        c->ksk_f, c->tw256);
     ev_end(c);
 }
+static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, uint64_t *acc)
+{
+    const int n = (int)c->p.n;
+    if (variant == 6) {
+        ev_begin(c, F_BR, "k_blind_rotate6", count);
+        hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+    } else if (variant == 5) {
+        size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
+        if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
+        ev_begin(c, F_BR, "k_blind_rotate5", count);
+        hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+    } else if (variant == 4) {
+        ev_begin(c, F_BR, "k_blind_rotate4", count);
+        hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+#ifdef TXD_WITH_BR3
+    } else if (variant == 3) {
+        ev_begin(c, F_BR, "k_blind_rotate3", count);
+        hipLaunchKernelGGL(k_blind_rotate3, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+#endif
+    } else {
+        ev_begin(c, F_BR, "k_blind_rotate", count);
+        hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+    }
+    ev_end(c);
+}
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
-    ev_begin(c, F_BR);
     // Same results bit for bit from every kernel; the choice is by launch size, in units per CU (measured on MI355X, n = 768):
     //   > 4   every SIMD can hold two units: k_blind_rotate5 (generated assembly, two waves per SIMD in one persistent
     //         512-thread workgroup per CU, fair arbitration between the two waves of a SIMD); k_blind_rotate4 (the same loop
@@ -391,37 +433,19 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     //         polynomial (tx_br2.hpp): 128 units 2.95 against 7.2 ms, 512 units 4.7 against 7.2 ms, 768 units 6.4-7.0
     //         against 7.5 ms.
     //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) four cooperative workgroups per CU load the
-    //         LDS store path and the vector pipes as fully as four one-wave units do and add two barriers per step: 7.9-8.5
+    //         LDS pipeline and the vector pipes as fully as four one-wave units do and add two barriers per step: 7.9-8.5
     //         against 7.5-8.2 ms for k_blind_rotate (one wave per unit, hipcc; TX_BR_VARIANT=0), which therefore runs here.
-    const int variant = c->br_variant >= 0 ? c->br_variant
-                        : (count > (size_t)4 * c->num_cus ? 5 : (count <= (size_t)3 * c->num_cus ? 6 : 0));
-    if (variant == 6) {
-        c->last_br_kernel = "k_blind_rotate6";
-        hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count,
-                           (int)c->p.n, c->bsk_f, c->tw);
-    } else
-    if (variant == 5) {
-        size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
-        if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
-        c->last_br_kernel = "k_blind_rotate5";
-        hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc,
-                           (int)count, (int)c->p.n, c->bsk_f, c->tw);
-    } else if (variant == 4) {
-        c->last_br_kernel = "k_blind_rotate4";
-        hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
-                           (int)c->p.n, c->bsk_f, c->tw);
-#ifdef TXD_WITH_BR3
-    } else if (variant == 3) {
-        c->last_br_kernel = "k_blind_rotate3";
-        hipLaunchKernelGGL(k_blind_rotate3, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count,
-                           (int)c->p.n, c->bsk_f, c->tw);
-#endif
-    } else {
-        c->last_br_kernel = "k_blind_rotate";
-        hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count,
-                           (int)c->p.n, c->bsk_f, c->tw);
-    }
-    ev_end(c);
+    // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
+    // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
+    // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).
+    const size_t cus = (size_t)c->num_cus;
+    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 0; };
+    if (c->br_variant >= 0) { launch_br(c, c->br_variant, in, count, acc); return; }
+    if (count <= 4 * cus) { launch_br(c, small(count), in, count, acc); return; }
+    const size_t pass = 8 * cus, rem = count % pass, full = count - rem;
+    if (full == 0 || rem == 0 || rem > 4 * cus) { launch_br(c, 5, in, count, acc); return; }
+    launch_br(c, 5, in, full, acc);
+    launch_br(c, small(rem), in + full * (c->p.n + 1), rem, acc + full * GL);
 }
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {
@@ -446,11 +470,11 @@ static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
     ev_end(c);
 }
 static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t *lut_set, size_t lut_stride, int nlut,
-                    uint64_t *out)
+                    uint64_t *out, const uint8_t *pos = nullptr)
 {
     ev_begin(c, F_LUT);
     hipLaunchKernelGGL(k_lut_eval, dim3(grid_for(nbytes * nlut * 2)), dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
-                       lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw);
+                       lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
     ev_end(c);
 }
 // KS + CBS of `count` big LWEs into Fourier GGSWs
@@ -538,10 +562,66 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
             hipLaunchKernelGGL(k_known_rotate, dim3(grid_for(bits)), dim3(256), 0, c->stream, c->d_bytes,
                                c->ctr_luts + (size_t)m * mult_sz, (size_t)2 * GL, c->sm + (size_t)m * nb * blkw, (int)bits);
         ev_end(c);
+        // Second round of a CTR batch: the state entering it is a public function of the counter blocks up to the first
+        // linear layer (the first round is a sample extraction at a PUBLIC index), so two blocks whose counters agree in
+        // the four bytes that feed a column hold the SAME 32 ciphertexts in that column -- bit for bit, the operations are
+        // deterministic -- and the circuit bootstraps and table look-ups of that column give the same result.  Counters of
+        // one batch differ in their last byte(s) only: of the 4 nb columns, 3 are shared by all blocks (until a carry into
+        // byte 14), so the round bootstraps each DISTINCT column once and copies (medium instance: 268 instead of 1024
+        // bytes).  From the third round on every column has mixed in a block's own byte.  Same ciphertexts as evaluating
+        // every column: tests compare with the oracle, which does; TX_CTR_SHARE=0 evaluates every column here too.
+        std::vector<int> col_of, rep_of(nb * 4);
+        if (c->ctr_share) {
+            std::vector<std::pair<uint64_t, int>> seen;        // (column, its four source counter bytes) -> compact index
+            for (size_t b = 0; b < nb; b++)
+                for (int col = 0; col < 4; col++) {
+                    uint64_t key = (uint64_t)col;
+                    for (int r = 0; r < 4; r++) key = (key << 8) | ctr[b * 16 + 4 * ((r + col) & 3) + r];   // k_linear forward: sh[r, col] = s[r, (r + col) % 4]
+                    int idx = -1;
+                    for (auto &kv : seen) if (kv.first == key) { idx = kv.second; break; }
+                    if (idx < 0) { idx = (int)col_of.size(); seen.push_back({key, idx}); col_of.push_back((int)(b * 4 + col)); }
+                    rep_of[b * 4 + col] = idx;
+                }
+        }
+        const size_t ucols = col_of.size();
+        const bool share = c->ctr_share && ucols < nb * 4;
+        if (share) {
+            if (c->share_tmp_bits < c->ws_blocks * 128) {
+                hipFree(c->share_tmp); c->share_tmp = nullptr; c->share_tmp_bits = 0;
+                HIP_OK(hipMalloc(&c->share_tmp, 3 * c->ws_blocks * 128 * BIG * 8));
+                c->share_tmp_bits = c->ws_blocks * 128;
+            }
+            if (c->idx_cap < nb * 4) {
+                hipFree(c->d_idx); hipFree(c->d_pos); c->d_idx = nullptr; c->d_pos = nullptr; c->idx_cap = 0;
+                HIP_OK(hipMalloc(&c->d_idx, 2 * c->ws_blocks * 4 * sizeof(int)));
+                HIP_OK(hipMalloc(&c->d_pos, c->ws_blocks * 16));
+                c->idx_cap = c->ws_blocks * 4;
+            }
+            std::vector<uint8_t> pos(ucols * 4);
+            for (size_t u = 0; u < ucols; u++)
+                for (int r = 0; r < 4; r++) pos[u * 4 + r] = (uint8_t)(4 * (col_of[u] & 3) + r);
+            HIP_OK(hipMemcpyAsync(c->d_idx, col_of.data(), ucols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(c->d_idx + c->idx_cap, rep_of.data(), nb * 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(c->d_pos, pos.data(), pos.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));       // the host vectors go out of scope
+        }
         for (int s = 1; s <= 9; s++) {
             ev_begin(c, F_LIN);
             hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 0);
             ev_end(c);
+            if (s == 1 && share) {
+                uint64_t *cst = c->res;                         // compact state: the distinct columns (c->res is free during the rounds)
+                ev_begin(c, F_LIN);
+                hipLaunchKernelGGL(k_gather_cols, dim3(ew_grid(ucols * 32 * BIG)), dim3(256), 0, c->stream, c->st, c->d_idx, cst, (int)ucols);
+                ev_end(c);
+                if (run_cbs(c, cst, ucols * 32, c->ggsw_f)) return -1;
+                run_lut(c, c->ggsw_f, ucols * 4, c->ctr_luts + (size_t)s * set_sz, mult_sz, 3, c->share_tmp, c->d_pos);
+                ev_begin(c, F_LIN);
+                hipLaunchKernelGGL(k_scatter_cols, dim3(ew_grid(3 * bits * BIG)), dim3(256), 0, c->stream, c->share_tmp,
+                                   c->d_idx + c->idx_cap, c->sm, (int)(nb * 4), (int)ucols, 3);
+                ev_end(c);
+                continue;
+            }
             if (run_cbs(c, c->st, bits, c->ggsw_f)) return -1;
             run_lut(c, c->ggsw_f, nb * 16, c->ctr_luts + (size_t)s * set_sz, mult_sz, s == 9 ? 1 : 3, c->sm);
         }

@@ -922,16 +922,18 @@ __device__ __forceinline__ void sample_extract_store(const uint64_t (&p0)[16], c
     if (w.lane == 0) o[2 * N] = w.pl[nth];
 }
 
+// pos: AES byte position (0..15) of every byte, i.e. which keyed table it takes; null = byte index mod 16 (whole blocks)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
                                                   size_t byte_stride, uint64_t *out, int nbytes, int nlut,
-                                                  const cplx *tw_g)
+                                                  const cplx *tw_g, const uint8_t *pos)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds);
     if (w.unit >= nbytes * nlut * 2) return;
     const int byte = w.unit / (nlut * 2), lut = (w.unit >> 1) % nlut, acc_idx = w.unit & 1;
     const int lane = w.lane;
-    const uint64_t *lp = luts + (size_t)lut * lut_stride + (size_t)(byte & 15) * byte_stride + (size_t)acc_idx * GL;
+    const int table = pos ? (int)pos[byte] : (byte & 15);
+    const uint64_t *lp = luts + (size_t)lut * lut_stride + (size_t)table * byte_stride + (size_t)acc_idx * GL;
     uint64_t acc[KP][16];
 #pragma unroll
     for (int q = 0; q < KP; q++)
@@ -1076,6 +1078,25 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *st, uint64_t *
         uint64_t v = st[(((size_t)blk * 128) + (size_t)sbyte * 8 + bit) * BIG + word];
         if (ctr && word == BIG - 1 && ((ct_bytes[blk * 16 + byte] >> bit) & 1)) v += (uint64_t)1 << 63;
         out[e] = v;
+    }
+}
+
+// State columns (32 LWEs = the four bytes of one AES column of one block) gathered into / scattered from a compact list:
+// the CTR schedule bootstraps every DISTINCT column of its second round once (tx_api.hip, ctr_round2_groups).
+//   gather:  out[u] = st[col[u]],  col[u] = block * 4 + column
+//   scatter: sm[lut][block * 4 + column] = in[lut][rep[block * 4 + column]]   for all nlut tables
+__global__ __launch_bounds__(256) void k_gather_cols(const uint64_t *st, const int *col, uint64_t *out, int ncols)
+{
+    const size_t cw = (size_t)32 * BIG, total = (size_t)ncols * cw;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = st[(size_t)col[e / cw] * cw + e % cw];
+}
+__global__ __launch_bounds__(256) void k_scatter_cols(const uint64_t *in, const int *rep, uint64_t *sm, int ncols_all, int ncols_in, int nlut)
+{
+    const size_t cw = (size_t)32 * BIG, per = (size_t)ncols_all * cw, total = per * nlut;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t lut = e / per, r = e % per;
+        sm[e] = in[(lut * ncols_in + (size_t)rep[r / cw]) * cw + r % cw];
     }
 }
 

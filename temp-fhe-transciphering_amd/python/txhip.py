@@ -29,7 +29,8 @@ class TxTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_keyswitch", "ms_blind_rotate", "ms_trace", "ms_scheme_switch",
                                           "ms_lut_eval", "ms_linear", "ms_total")] + \
                [(n, C.c_uint32) for n in ("n_keyswitch", "n_blind_rotate", "n_trace", "n_scheme_switch",
-                                          "n_lut_eval", "n_linear")]
+                                          "n_lut_eval", "n_linear", "n_br_main")] + \
+               [("ms_br_main", C.c_double), ("units_br_main", C.c_uint64)]
 
 
 EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys", "tx_eval_key_words",

@@ -19,9 +19,11 @@ def test_algorithmic_bytes_match_survey():
     assert abs(b.algorithmic_bytes_per_block(8) - 1.9165e9) < 2e6
     assert abs(b.algorithmic_bytes_per_block(64) - 1.8557e9) < 2e6
     # blind-rotation launch: 128 bits per block x (6152 B in + 24576 B out) = 3.93 MB per block, + BSK 56.6 MB
-    per_block = (b.br_launch_bytes(2, 768) - b.br_launch_bytes(1, 768))
+    per_block = (b.br_launch_bytes(2 * 128, 768) - b.br_launch_bytes(128, 768))          # units = bits: 128 per block
     assert abs(per_block - 3.93e6) < 0.01e6
-    assert abs(b.br_launch_bytes(1, 768) - per_block - 56.62e6) < 0.01e6
+    assert abs(b.br_launch_bytes(128, 768) - per_block - 56.62e6) < 0.01e6
+    # several launches: the key is streamed once per launch (CTR: eight of 8192 units and one of 2144)
+    assert b.br_launch_bytes(8 * 8192 + 2144, 768, 9) == 8 * b.br_launch_bytes(8192, 768) + b.br_launch_bytes(2144, 768)
     assert b.HBM_PEAK_GBS == 8000.0
 
 

@@ -207,6 +207,38 @@ def test_ctr_full_schedule_bit_identical_to_oracle(rig768):
     assert np.array_equal(one, r.eng.transcipher(ct[:32], iv=AES_IV)[:128])
 
 
+def test_ctr_shared_columns_equal_full_evaluation(rig256, monkeypatch):
+    """CTR batches bootstrap each DISTINCT column of their second round once (blocks whose counters agree in the four bytes
+    feeding a column hold the same ciphertexts there).  Five blocks whose counters run ..fe, ..ff, then carry into byte 14
+    (columns 0 and 1 both change), and a batch whose IV wraps around 2^128: bit-identical to the engine with sharing off
+    (TX_CTR_SHARE=0), to the oracle (which evaluates every column), and block-wise to single-block runs (no sharing
+    possible there)"""
+    import txhip
+    import txdist
+    r = rig256
+    rng = np.random.default_rng(55)
+    ct = rng.integers(0, 256, 16 * 5, dtype=np.uint8).tobytes()
+    monkeypatch.setenv("TX_CTR_SHARE", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    e0.load_ctr_luts(r.ctr_luts)
+    monkeypatch.delenv("TX_CTR_SHARE")
+    for iv in (AES_IV[:14] + b"\x07\xfe", bytes([0xFF] * 15) + b"\xfd"):
+        shared = r.eng.transcipher(ct, iv=iv)
+        assert np.array_equal(shared, e0.transcipher(ct, iv=iv))
+        assert np.array_equal(shared[:256], r.octx.transcipher_ctr(r.ctr_luts, iv, ct[:32]))
+        for b in (0, 2, 4):
+            assert np.array_equal(shared[128 * b:128 * b + 128], r.eng.transcipher(ct[16 * b:16 * b + 16], iv=txdist.iv_add(iv, b)))
+    # the timing record shows the smaller second round: 5 blocks = 20 columns, 2 + 2 + ... distinct
+    r.eng.transcipher(ct, iv=AES_IV)
+    t_sh = r.eng.timing()
+    e0.transcipher(ct, iv=AES_IV)
+    t_full = e0.timing()
+    assert t_full["units_br_main"] == 9 * 5 * 128
+    assert t_sh["units_br_main"] == 8 * 5 * 128 + (5 + 3) * 32          # column 0 per block + three shared columns
+    e0.close()
+
+
 def test_medium_instance_ctr_fixture_decrypts_exactly(rig768):
     """BASELINE config 3 on the harness's own medium data (CTR, golden fixture): 64 blocks; then the homomorphic max
     (512 values, 9 tournament levels) and inner product (256 pairs) over the transciphered bits, decrypted and
