@@ -200,6 +200,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the same instance with every column of the CTR schedule's second round evaluated (no sharing): reported beside `value`
+    value_unshared = None
+    if world == 1 and args.mode == "ctr" and not args.no_ctr_share:
+        os.environ["TX_CTR_SHARE"] = "0"
+        eng2 = txhip.Engine(p, device=dev_index)
+        del os.environ["TX_CTR_SHARE"]
+        eng2.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
+        eng2.load_ctr_luts(luts)
+        out2 = torch.empty((n_blocks * 128, words), dtype=torch.int64, device=dev)
+        eng2.transcipher(ct, iv, out_device_ptr=out2.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eng2.transcipher(ct, iv, out_device_ptr=out2.data_ptr())
+        torch.cuda.synchronize()
+        value_unshared = n_blocks * 2 / (time.perf_counter() - t0)
+        same = bool(torch.equal(out2, step()))            # the two schedules give the same ciphertexts, bit for bit
+        eng2.close()
+        if not same:
+            raise SystemExit("bench.py: shared and unshared CTR schedules differ; no number reported")
+
     if rank == 0:
         _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
@@ -237,7 +258,7 @@ def main():
                                  "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES, "
                                  "profiles/r2c_pmc_sq_blind_rotate5.csv)"},
             "ctr_shared_columns": (None if args.mode != "ctr" else
-                                   {"enabled": not args.no_ctr_share,
+                                   {"enabled": not args.no_ctr_share, "value_without_sharing": value_unshared,
                                     "note": "CTR: the state entering the second round is a public function of the counters, so columns fed by "
                                             "the same counter bytes hold the same ciphertexts in every block; each distinct column is "
                                             "bootstrapped once (64 consecutive counters: 268 of 1024 bytes in that round, the other 8 "
