@@ -200,6 +200,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    t_ms, t_launches, t_units = br_ms[0], br_launches[0], br_units[0]      # blind-rotation totals of the timed region
     # the same instance with every column of the CTR schedule's second round evaluated (no sharing): reported beside `value`
     value_unshared = None
     if world == 1 and args.mode == "ctr" and not args.no_ctr_share:
@@ -224,13 +225,13 @@ def main():
     if rank == 0:
         _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
-        br_avg_ms = br_ms[0] / max(1, br_launches[0])
-        br_avg_units = br_units[0] / max(1, br_launches[0])
+        br_avg_ms = t_ms / max(1, t_launches)
+        br_avg_units = t_units / max(1, t_launches)
         br_kernel = eng.last_blind_rotate_kernel()         # what run_br (csrc/tx_api.hip) launched, as the library reports it
         # all launches of that kernel in the timed region (they differ in size: in CTR mode the second round bootstraps
         # only the distinct state columns): algorithmic bytes of all of them over the time of all of them
-        achieved = br_launch_bytes(br_units[0], args.n, br_launches[0]) / (br_ms[0] * 1e-3) / 1e9
-        br_flops = br_units[0] * args.n * BR_F64_FLOP_PER_UNIT_STEP
+        achieved = br_launch_bytes(t_units, args.n, t_launches) / (t_ms * 1e-3) / 1e9
+        br_flops = t_units * args.n * BR_F64_FLOP_PER_UNIT_STEP
         default_mix = (m_local == 64 and args.n == 768 and args.mode == "ctr" and not args.no_ctr_share and br_kernel == "k_blind_rotate5")
         line = {
             "metric": "AES blocks transciphered/sec (medium instance)", "value": value, "unit": "AES blocks/s",
@@ -244,12 +245,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (BR_TRAFFIC_AVG_DEFAULT_MIX if default_mix else
                                      (BR_TRAFFIC_BYTES_8192.get(br_kernel) if abs(br_avg_units - 8192) < 0.5 and args.n == 768 else None)),
-                         "avg_launch_ms": br_avg_ms, "launches": br_launches[0], "avg_units_per_launch": br_avg_units,
-                         "algorithmic_bytes_per_launch": br_launch_bytes(br_units[0], args.n, br_launches[0]) / max(1, br_launches[0]),
+                         "avg_launch_ms": br_avg_ms, "launches": t_launches, "avg_units_per_launch": br_avg_units,
+                         "algorithmic_bytes_per_launch": br_launch_bytes(t_units, args.n, t_launches) / max(1, t_launches),
                          "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,
                          "path_frac": value / world * algorithmic_bytes_per_block(m_local) / 1e9 / HBM_PEAK_GBS,
-                         "fp64_valu": {"achieved_TFLOPs": br_flops / (br_ms[0] * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
-                                       "frac": br_flops / (br_ms[0] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "fp64_valu": {"achieved_TFLOPs": br_flops / (t_ms * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                                       "frac": br_flops / (t_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                          "vector_pipe_busy_pmc": (BR_VALU_BUSY_PMC.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
                          "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
                                  "fp64_valu counts FP64 flops against the FMA peak at the nominal clock (half of this loop's FP64 "

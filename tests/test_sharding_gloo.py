@@ -49,18 +49,20 @@ def _worker(rank, world, port, mode, q, nb=3):
         rk = O.aes_expand(key)
         ct, luts, ivv = b"".join(O.aes_encrypt_block(rk, pt[i:i + 16]) for i in range(0, len(pt), 16)), keys.round_luts(key), None
 
+    kept = {}
+
     def local_fn(ct_slab, iv_slab, n_local, n_pad):
         out = torch.zeros((n_pad * 128, ctx.big), dtype=torch.int64)
         if n_local:
             r = ctx.transcipher_ctr(luts, iv_slab, ct_slab) if mode == "ctr" else ctx.transcipher(luts, ct_slab)
             out[: n_local * 128] = torch.from_numpy(r.view(np.int64))
+        kept["mine"] = out[: n_local * 128]               # this rank's slab, as the sharded max consumes it
         return out
 
     res = txdist.transcipher_sharded(local_fn, ct, ivv, rank, world, dist)
     # the max mini-workload over the sharded result: local tournament, gather of the partial maxima, final tournament
     _, n_local = txdist.shard(nb, world, rank)
-    mine = local_fn(ct[16 * txdist.shard(nb, world, rank)[0]:16 * (txdist.shard(nb, world, rank)[0] + n_local)],
-                    txdist.iv_add(ivv, txdist.shard(nb, world, rank)[0]) if ivv is not None else None, n_local, n_local)
+    mine = kept["mine"]
 
     def local_max(t):
         return torch.from_numpy(ctx.max_u16(np.ascontiguousarray(t.numpy().view(np.uint64)), tournament=True).view(np.int64))

@@ -312,6 +312,15 @@ class Emu:
     def op_v_lshl_add_u32(self, d, a, b, c): self.wr32(d, (self.rd32(a) << (self.rd32(b) & 31)) + self.rd32(c))
     def op_v_add3_u32(self, d, a, b, c): self.wr32(d, self.rd32(a) + self.rd32(b) + self.rd32(c))
 
+    def op_v_ashrrev_i32(self, d, a, b):
+        self.wr32(d, (self.rd32(b).view(np.int32) >> (self.rd32(a) & 31).astype(np.int32)).view(np.uint32))
+    def op_v_lshl_or_b32(self, d, a, b, c): self.wr32(d, (self.rd32(a) << (self.rd32(b) & 31)) | self.rd32(c))
+    def op_v_cndmask_b32(self, d, a, b, m):
+        """VOP3 form: lane mask in an SGPR pair (set by scalar moves: wave-uniform selects)"""
+        bits = int(self.s[m.i]) | (int(self.s[m.i + 1]) << 32)
+        lanes = np.array([(bits >> l) & 1 for l in range(64)], bool)
+        self.wr32(d, np.where(lanes, self.rd32(b), self.rd32(a)))
+
     def op_v_alignbit_b32(self, d, hi, lo, sh):
         x = (self.rd32(hi).astype(np.uint64) << np.uint64(32)) | self.rd32(lo).astype(np.uint64)
         self.wr32(d, (x >> (self.rd32(sh).astype(np.uint64) & np.uint64(31))) & np.uint64(0xFFFFFFFF))
