@@ -36,6 +36,14 @@ def test_cooperative_loop_equals_oracle_three_waves(oracle):
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
 
 
+def test_cooperative_trace_experiment_equals_oracle_two_waves(oracle):
+    """tools/asmgen/trgen2.py (two waves per unit: A the low-split pass, B the high-split pass, mask polynomials in
+    registers; an experiment that is NOT in the library -- it measured slower than the one-wave loop, DESIGN.md section 11 --
+    kept runnable): two emulated waves in both scheduling orders against txo_trace() with real keys, ten steps"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_trace2.py"), "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
+
+
 def test_stamped_variant_is_the_same_arithmetic(oracle):
     env = dict(os.environ, BR_STAMPS="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "5"], capture_output=True, text=True, timeout=600, env=env)
@@ -132,9 +140,9 @@ def test_register_budget_and_no_scratch():
     """the generated loops fit 256 VGPRs and issue no scratch instruction (what hipcc keeps around them is bounded by
     test_scratch_of_the_built_kernels): two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, brgen3, trgen, ssgen, gcn
+    import brgen, brgen3, trgen, trgen2, ssgen, gcn
     for prog, budget in ((brgen.Gen().build(), 256), (trgen.TraceGen().build(), 256), (ssgen.SsGen().build(), 256),
-                         (brgen3.CoopGen().build(), 168)):
+                         (brgen3.CoopGen().build(), 168), (trgen2.Trace2Gen().build(), 256)):
         top = 0
         for i in prog.ins:
             for x in i.a:
