@@ -125,3 +125,25 @@ def test_install_layout_for_the_reference_harness(tmp_path):
     assert r.returncode == 1 and "Usage" in r.stderr
     r = subprocess.run([str(prefix / "client_postprocess"), "7"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "size must be" in r.stderr
+
+
+def test_timing_struct_layout_matches_the_python_binding(tmp_path):
+    """tx_timing grew in round 3 (per-kernel blind-rotation totals): size and field offsets of the C struct, as a C
+    compiler lays them out, are what txhip.TxTiming (ctypes) assumes; same for tx_params"""
+    import subprocess
+    import txhip
+    fields_t = [n for n, _ in txhip.TxTiming._fields_]
+    fields_p = [n for n, _ in txhip.TxParams._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tfhe_mi355x.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(tx_timing));\n' +
+                   "".join('  printf("%%zu\\n", offsetof(tx_timing, %s));\n' % f for f in fields_t) +
+                   '  printf("%zu\\n", sizeof(tx_params));\n' +
+                   "".join('  printf("%%zu\\n", offsetof(tx_params, %s));\n' % f for f in fields_p) +
+                   '  return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    want = [C.sizeof(txhip.TxTiming)] + [getattr(txhip.TxTiming, f).offset for f in fields_t] + \
+           [C.sizeof(txhip.TxParams)] + [getattr(txhip.TxParams, f).offset for f in fields_p]
+    assert got == want
