@@ -159,8 +159,14 @@ def main():
     words = 2 * 1024 + 1
     br_ms, br_launches, br_units = [0.0], [0], [0]
 
+    out_bufs = {}
+
     def local_fn(ct_slab, iv_slab, n_local, n_pad):
-        out = torch.empty((n_pad * 128, words), dtype=torch.int64, device=dev)
+        # the result buffer (134 MB for 64 blocks) is allocated once and reused by every step: the library writes the
+        # LWEs of the step into it (`out_is_device`), nothing is carried over
+        out = out_bufs.get(n_pad)
+        if out is None:
+            out = out_bufs[n_pad] = torch.empty((n_pad * 128, words), dtype=torch.int64, device=dev)
         if n_local:
             eng.transcipher(ct_slab, iv_slab, out_device_ptr=out.data_ptr())
             tm = eng.timing()

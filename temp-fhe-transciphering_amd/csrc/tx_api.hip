@@ -59,7 +59,11 @@ struct tx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     tx_timing timing;
+#ifdef TXD_NO_EVENTS   // experiment: what the per-kernel HIP events cost (tools/wall_time.py)
+    bool time_enabled = false;
+#else
     bool time_enabled = true;
+#endif
 };
 
 extern "C" void tx_params_aes_tight(tx_params *p)
