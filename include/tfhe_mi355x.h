@@ -87,6 +87,12 @@ int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words);
 int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
                    uint64_t *out_lwe, int out_is_device);
 
+/* Host logic of the CTR schedule's shared second round, exposed for tests and tooling (needs no context and no GPU): for the
+ * counter blocks iv + first_block + b, b < n_blocks, rep_of[b * 4 + c] is the index (into col_of) of the distinct column that
+ * column c of block b equals, col_of[k] = block * 4 + column of the k-th distinct column.  Both arrays hold n_blocks * 4
+ * ints.  Returns the number of distinct columns (what the second round bootstraps), negative on error. */
+int tx_ctr_shared_columns(const uint8_t *iv, size_t first_block, size_t n_blocks, int *rep_of, int *col_of);
+
 /* Same schedule stopped after `rounds_done` bootstrapped rounds (0..9), state returned in the
  * reference's internal order (LSB first); used by the parity tests only. */
 int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, int rounds_done,

@@ -506,6 +506,44 @@ static int run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw_
 }
 static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 4096 ? 4096 : g); }
 
+// ---- CTR: which state columns of the second round hold the same ciphertexts (host logic, no GPU) ----
+// ctr: nb counter blocks of 16 bytes.  Column col of block b entering the second round is built (k_linear, forward:
+// sh[r, col] = s[r, (r + col) % 4]) from the first-round table entries of counter bytes 4 ((r + col) % 4) + r, r = 0..3.
+// rep_of[b * 4 + col] = index into col_of of the first (block, column) with the same column index and the same four bytes.
+static void ctr_round2_groups(const uint8_t *ctr, size_t nb, std::vector<int> &rep_of, std::vector<int> &col_of)
+{
+    std::vector<std::pair<uint64_t, int>> seen;
+    rep_of.assign(nb * 4, 0); col_of.clear();
+    for (size_t b = 0; b < nb; b++)
+        for (int col = 0; col < 4; col++) {
+            uint64_t key = (uint64_t)col;
+            for (int r = 0; r < 4; r++) key = (key << 8) | ctr[b * 16 + 4 * ((r + col) & 3) + r];
+            int idx = -1;
+            for (auto &kv : seen) if (kv.first == key) { idx = kv.second; break; }
+            if (idx < 0) { idx = (int)col_of.size(); seen.push_back({key, idx}); col_of.push_back((int)(b * 4 + col)); }
+            rep_of[b * 4 + col] = idx;
+        }
+}
+static void ctr_blocks(const uint8_t *iv, size_t blk0, size_t nb, std::vector<uint8_t> &ctr)
+{   // iv + (blk0 + b), 128-bit big-endian (harness/aes_keygen_and_encrypt.py:52-54)
+    ctr.resize(nb * 16);
+    for (size_t b = 0; b < nb; b++) {
+        uint8_t *p = &ctr[b * 16]; memcpy(p, iv, 16);
+        uint64_t add = blk0 + b;
+        for (int i = 15; i >= 0 && add; i--) { uint64_t v = (uint64_t)p[i] + (add & 0xFF); p[i] = (uint8_t)v; add = (add >> 8) + (v >> 8); }
+    }
+}
+extern "C" int tx_ctr_shared_columns(const uint8_t *iv, size_t first_block, size_t n_blocks, int *rep_of, int *col_of)
+{
+    if (!iv || !rep_of || !col_of) return fail("tx_ctr_shared_columns: null argument");
+    std::vector<uint8_t> ctr; std::vector<int> rep, cols;
+    ctr_blocks(iv, first_block, n_blocks, ctr);
+    ctr_round2_groups(ctr.data(), n_blocks, rep, cols);
+    std::copy(rep.begin(), rep.end(), rep_of);
+    std::copy(cols.begin(), cols.end(), col_of);
+    return (int)cols.size();
+}
+
 // ---- a1: round schedules ----
 static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint8_t *iv, size_t blk0, int rounds_done,
                              uint64_t *d_out, bool reference_order)
@@ -552,12 +590,8 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
     } else {
         if (!c->ctr_luts) return fail("tx_transcipher: CTR LUTs not loaded");
         const size_t set_sz = 3 * mult_sz;
-        std::vector<uint8_t> ctr(nb * 16);
-        for (size_t b = 0; b < nb; b++) {           // iv + (blk0 + b), 128-bit big-endian
-            uint8_t *p = &ctr[b * 16]; memcpy(p, iv, 16);
-            uint64_t add = blk0 + b;
-            for (int i = 15; i >= 0 && add; i--) { uint64_t v = (uint64_t)p[i] + (add & 0xFF); p[i] = (uint8_t)v; add = (add >> 8) + (v >> 8); }
-        }
+        std::vector<uint8_t> ctr;
+        ctr_blocks(iv, blk0, nb, ctr);
         HIP_OK(hipMemcpyAsync(c->d_bytes, ctr.data(), nb * 16, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(c->d_ct, ct, nb * 16, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
@@ -575,18 +609,7 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
         // bytes).  From the third round on every column has mixed in a block's own byte.  Same ciphertexts as evaluating
         // every column: tests compare with the oracle, which does; TX_CTR_SHARE=0 evaluates every column here too.
         std::vector<int> col_of, rep_of(nb * 4);
-        if (c->ctr_share) {
-            std::vector<std::pair<uint64_t, int>> seen;        // (column, its four source counter bytes) -> compact index
-            for (size_t b = 0; b < nb; b++)
-                for (int col = 0; col < 4; col++) {
-                    uint64_t key = (uint64_t)col;
-                    for (int r = 0; r < 4; r++) key = (key << 8) | ctr[b * 16 + 4 * ((r + col) & 3) + r];   // k_linear forward: sh[r, col] = s[r, (r + col) % 4]
-                    int idx = -1;
-                    for (auto &kv : seen) if (kv.first == key) { idx = kv.second; break; }
-                    if (idx < 0) { idx = (int)col_of.size(); seen.push_back({key, idx}); col_of.push_back((int)(b * 4 + col)); }
-                    rep_of[b * 4 + col] = idx;
-                }
-        }
+        if (c->ctr_share) ctr_round2_groups(ctr.data(), nb, rep_of, col_of);
         const size_t ucols = col_of.size();
         const bool share = c->ctr_share && ucols < nb * 4;
         if (share) {

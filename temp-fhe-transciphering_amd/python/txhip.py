@@ -38,7 +38,7 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
            "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles",
-           "tx_last_blind_rotate_kernel"]
+           "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns"]
 
 _LIB = None
 
@@ -72,6 +72,7 @@ def lib():
         L.tx_stage_lut_eval.argtypes = [C.c_void_p, f64p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p]
         L.tx_get_timing.argtypes = [C.c_void_p, C.POINTER(TxTiming)]
         L.tx_get_twiddles.argtypes = [C.c_void_p, f64p]
+        L.tx_ctr_shared_columns.argtypes = [u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tx_last_blind_rotate_kernel.restype = C.c_char_p
         L.tx_last_blind_rotate_kernel.argtypes = [C.c_void_p]
         _LIB = L
@@ -88,6 +89,17 @@ def aes_tight(n=768):
     lib().tx_params_aes_tight(C.byref(p))
     p.n = n
     return p
+
+
+def ctr_shared_columns(iv, first_block, n_blocks):
+    """(rep_of [n_blocks * 4], col_of [distinct]) of the CTR schedule's second round (host logic, no GPU)"""
+    ivb = np.frombuffer(bytes(iv), np.uint8).copy()
+    rep = np.zeros(n_blocks * 4, np.int32)
+    col = np.zeros(n_blocks * 4, np.int32)
+    k = lib().tx_ctr_shared_columns(_p8(ivb), first_block, n_blocks, rep.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)))
+    if k < 0:
+        raise TxError(lib().tx_last_error().decode())
+    return rep, col[:k]
 
 
 class Engine:

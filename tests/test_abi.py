@@ -147,3 +147,81 @@ def test_timing_struct_layout_matches_the_python_binding(tmp_path):
     want = [C.sizeof(txhip.TxTiming)] + [getattr(txhip.TxTiming, f).offset for f in fields_t] + \
            [C.sizeof(txhip.TxParams)] + [getattr(txhip.TxParams, f).offset for f in fields_p]
     assert got == want
+
+
+def test_ctr_shared_columns_are_exactly_the_equal_columns_of_cleartext_aes():
+    """host logic of the CTR schedule's shared second round (tx_ctr_shared_columns, no GPU): two (block, column) pairs are
+    put in one group exactly when the cleartext state entering the second round -- AddRoundKey(0), SubBytes, ShiftRows,
+    MixColumns of the counter blocks, computed here with the client library's AES tables -- agrees in that column for
+    EVERY key tried (the grouping may not depend on the key); consecutive counters, a carry into byte 14, a wrap around
+    2^128 and a first_block offset"""
+    import txhip
+    import txclient
+    import oracle_lib as O
+
+    def gm(a, b):
+        x = 0
+        for _ in range(8):
+            if b & 1: x ^= a
+            a = ((a << 1) ^ 0x1B) & 0xFF if a & 0x80 else a << 1
+            b >>= 1
+        return x
+
+    rng = np.random.default_rng(3)
+    cases = [(bytes.fromhex("64b92e64992534e495b9da182409427c"), 0, 64), (bytes(14) + b"\x07\xfe", 0, 5),
+             (bytes([0xFF] * 15) + b"\xfd", 0, 6), (bytes.fromhex("64b92e64992534e495b9da182409427c"), 120, 300)]
+    for iv, first, nb in cases:
+        rep, col = txhip.ctr_shared_columns(iv, first, nb)
+        assert rep.shape[0] == nb * 4 and col.shape[0] == rep.max() + 1
+        cols_by_key = []
+        for trial in range(3):
+            key = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
+            rk = O.aes_expand(key).reshape(11, 16)
+            state_cols = np.zeros((nb, 4, 4), np.uint8)
+            for b in range(nb):
+                ctr = ((int.from_bytes(iv, "big") + first + b) % (1 << 128)).to_bytes(16, "big")
+                # the first round of cleartext AES on the counter block (S-box computed below from the field inverse)
+                s = bytes(a ^ k for a, k in zip(ctr, rk[0]))
+                sb = bytes(SBOX[v] for v in s)
+                sh = bytes(sb[4 * ((c + r) % 4) + r] for c in range(4) for r in range(4))
+                for c in range(4):
+                    colv = sh[4 * c:4 * c + 4]
+                    state_cols[b, c] = [gm(colv[r], 2) ^ gm(colv[(r + 1) % 4], 3) ^ colv[(r + 2) % 4] ^ colv[(r + 3) % 4] for r in range(4)]
+            cols_by_key.append(state_cols)
+        for b in range(nb):
+            for c in range(4):
+                b2, c2 = divmod(int(col[rep[b * 4 + c]]), 4)
+                assert c2 == c
+                for st in cols_by_key:
+                    assert np.array_equal(st[b, c], st[b2, c])              # grouped => equal for every key
+        # and distinct groups of one column index differ for at least one of the keys (no sharing is missed)
+        for c in range(4):
+            groups = sorted(set(int(rep[b * 4 + c]) for b in range(nb)))
+            reps = [divmod(int(col[g]), 4)[0] for g in groups]
+            for i in range(len(reps)):
+                for j in range(i + 1, min(len(reps), i + 40)):
+                    assert any(not np.array_equal(st[reps[i], c], st[reps[j], c]) for st in cols_by_key)
+    rep, col = txhip.ctr_shared_columns(bytes.fromhex("64b92e64992534e495b9da182409427c"), 0, 64)
+    assert col.shape[0] == 67                                                     # the medium instance: 64 + 3 distinct columns
+
+
+def _aes_sbox():
+    def gm(a, b):
+        x = 0
+        for _ in range(8):
+            if b & 1: x ^= a
+            a = ((a << 1) ^ 0x1B) & 0xFF if a & 0x80 else a << 1
+            b >>= 1
+        return x
+    s = [0] * 256
+    for x in range(256):
+        y = next(v for v in range(1, 256) if gm(x, v) == 1) if x else 0
+        r, t = y, y
+        for _ in range(4):
+            r = ((r << 1) | (r >> 7)) & 0xFF
+            t ^= r
+        s[x] = t ^ 0x63
+    return s
+
+
+SBOX = _aes_sbox()
