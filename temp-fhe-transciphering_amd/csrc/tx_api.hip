@@ -442,6 +442,7 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
     // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
     // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).
+    if (count == 0) return;
     const size_t cus = (size_t)c->num_cus;
     auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 0; };
     if (c->br_variant >= 0) { launch_br(c, c->br_variant, in, count, acc); return; }
