@@ -429,16 +429,18 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
 }
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 {
-    // Same results bit for bit from every kernel; the choice is by launch size, in units per CU (measured on MI355X, n = 768):
+    // Same results bit for bit from every kernel; the choice is by launch size, in units per CU (measured on MI355X, n = 768,
+    // inside the round pipeline, i.e. under sustained load):
     //   > 4   every SIMD can hold two units: k_blind_rotate5 (generated assembly, two waves per SIMD in one persistent
     //         512-thread workgroup per CU, fair arbitration between the two waves of a SIMD); k_blind_rotate4 (the same loop
     //         in two independent 256-thread workgroups per CU) is 1 % behind it (TX_BR_VARIANT=4).
     //   <= 3  the launch time is the length of ONE CMux chain: k_blind_rotate6 puts three waves on every unit, one per
-    //         polynomial (tx_br2.hpp): 128 units 2.95 against 7.2 ms, 512 units 4.7 against 7.2 ms, 768 units 6.4-7.0
-    //         against 7.5 ms.
-    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) four cooperative workgroups per CU load the
-    //         LDS pipeline and the vector pipes as fully as four one-wave units do and add two barriers per step: 7.9-8.5
-    //         against 7.5-8.2 ms for k_blind_rotate (one wave per unit, hipcc; TX_BR_VARIANT=0), which therefore runs here.
+    //         polynomial (tx_br2.hpp): 128 and 256 units 2.9 against 7.1 ms for the one-wave kernel, 512 units 4.5 against
+    //         7.4 ms, 768 units 6.1 against 7.5 ms.
+    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) twelve cooperative waves per CU queue at the LDS
+    //         pipeline and only tie with four one-wave units (7.7-8.1 against 7.5 ms), and a two-to-one split over two waves
+    //         per unit (tools/asmgen/brgen2.py) wins 3-9 % standalone and loses 3 % under sustained load: k_blind_rotate (one
+    //         wave per unit, hipcc; TX_BR_VARIANT=0: the plain form of the algorithm) runs here.
     // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
     // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
     // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).

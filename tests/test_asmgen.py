@@ -36,6 +36,20 @@ def test_cooperative_loop_equals_oracle_three_waves(oracle):
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
 
 
+def test_paired_loops_equal_oracle_two_waves(oracle):
+    """tools/asmgen/brgen2.py (two waves per unit, A = the mask polynomials and columns 0, 1, B = the body and column 2; two
+    different programs; an experiment that is NOT in the library -- faster than the one-wave kernel standalone, slower under
+    the pipeline's sustained load, DESIGN.md section 11 -- kept runnable): two emulated waves sharing the LDS image and
+    meeting at both barriers of every step, in both scheduling orders, against the oracle-built reference; without the
+    barriers it must NOT match"""
+    exe = os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate2.py")
+    for steps, seed in ((3, 1), (2, 77)):
+        r = subprocess.run([sys.executable, exe, str(steps), str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, exe, "2", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR2_ABL="B"))
+    assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
+
+
 def test_cooperative_trace_experiment_equals_oracle_two_waves(oracle):
     """tools/asmgen/trgen2.py (two waves per unit: A the low-split pass, B the high-split pass, mask polynomials in
     registers; an experiment that is NOT in the library -- it measured slower than the one-wave loop, DESIGN.md section 11 --
@@ -140,9 +154,10 @@ def test_register_budget_and_no_scratch():
     """the generated loops fit 256 VGPRs and issue no scratch instruction (what hipcc keeps around them is bounded by
     test_scratch_of_the_built_kernels): two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, brgen3, trgen, trgen2, ssgen, gcn
+    import brgen, brgen2, brgen3, trgen, trgen2, ssgen, gcn
     for prog, budget in ((brgen.Gen().build(), 256), (trgen.TraceGen().build(), 256), (ssgen.SsGen().build(), 256),
-                         (brgen3.CoopGen().build(), 168), (trgen2.Trace2Gen().build(), 256)):
+                         (brgen3.CoopGen().build(), 168), (trgen2.Trace2Gen().build(), 256),
+                         (brgen2.PairGen("A").build(), 256), (brgen2.PairGen("B").build(), 192)):
         top = 0
         for i in prog.ins:
             for x in i.a:

@@ -229,13 +229,14 @@ def test_ctr_shared_columns_equal_full_evaluation(rig256, monkeypatch):
         assert np.array_equal(shared[:256], r.octx.transcipher_ctr(r.ctr_luts, iv, ct[:32]))
         for b in (0, 2, 4):
             assert np.array_equal(shared[128 * b:128 * b + 128], r.eng.transcipher(ct[16 * b:16 * b + 16], iv=txdist.iv_add(iv, b)))
-    # the timing record shows the smaller second round: 5 blocks = 20 columns, 2 + 2 + ... distinct
-    r.eng.transcipher(ct, iv=AES_IV)
+    # the timing record shows the smaller second round (four blocks: every launch is k_blind_rotate6's size): 16 columns,
+    # column 0 of each block + three shared ones are distinct
+    r.eng.transcipher(ct[:64], iv=AES_IV)
     t_sh = r.eng.timing()
-    e0.transcipher(ct, iv=AES_IV)
+    e0.transcipher(ct[:64], iv=AES_IV)
     t_full = e0.timing()
-    assert t_full["units_br_main"] == 9 * 5 * 128
-    assert t_sh["units_br_main"] == 8 * 5 * 128 + (5 + 3) * 32          # column 0 per block + three shared columns
+    assert t_full["units_br_main"] == 9 * 4 * 128
+    assert t_sh["units_br_main"] == 8 * 4 * 128 + (4 + 3) * 32
     e0.close()
 
 
