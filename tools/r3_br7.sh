@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r3_br7.sh <tag>: the paired blind rotation on the GPU -- parity against the one-wave kernel, then timings
+# tools/r3_br7.sh <tag>: the paired blind-rotation EXPERIMENT (TX_BR_VARIANT=7; needs a library with tools/asmgen/k_blind_rotate7.hip.txt pasted in, see there) -- parity against the one-wave kernel, then timings
 set -e
 tag=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
