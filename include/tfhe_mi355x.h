@@ -146,6 +146,10 @@ int tx_get_timing(tx_ctx *c, tx_timing *t);
  * "k_blind_rotate", ...; "" before the first call).  The dispatch is by launch size (and the TX_BR_VARIANT experiment
  * knob, read once by tx_create): the measurement reports what ran, not what a copy of the rule predicts. */
 const char *tx_last_blind_rotate_kernel(const tx_ctx *c);
+/* Host logic of that dispatch, exposed for tests and tooling (no context, no GPU): the launches a blind rotation of `count`
+ * units is split into on a chip of num_cus CUs -- kernel number (5 = k_blind_rotate5, 6 = k_blind_rotate6, 0 = k_blind_rotate)
+ * and units of each, in unit order; both arrays hold two entries.  Returns the number of launches (0..2), negative on error. */
+int tx_plan_blind_rotate(size_t count, int num_cus, int *variants, size_t *counts);
 
 /* the forward-transform twiddle table [15][64] complex used by the kernels (for table pinning): eight pass-A rows
  * with the lane part of the twist folded in, seven pass-B rows */

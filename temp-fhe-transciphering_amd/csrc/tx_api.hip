@@ -402,6 +402,27 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
                        c->ksk_f, c->tw256);
     ev_end(c);
 }
+// which kernel(s) a blind rotation of `count` units runs on a chip of `cus` CUs (host logic, no GPU; the rule is explained
+// in run_br): at most two launches, in unit order.  forced >= 0: one launch of that kernel.
+static int br_plan(size_t count, int cus_, int forced, int variants[2], size_t counts[2])
+{
+    if (count == 0) return 0;
+    const size_t cus = (size_t)(cus_ > 0 ? cus_ : 1);
+    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 0; };
+    if (forced >= 0) { variants[0] = forced; counts[0] = count; return 1; }
+    if (count <= 4 * cus) { variants[0] = small(count); counts[0] = count; return 1; }
+    const size_t pass = 8 * cus, rem = count % pass, full = count - rem;
+    if (full == 0 || rem == 0 || rem > 4 * cus) { variants[0] = 5; counts[0] = count; return 1; }
+    variants[0] = 5; counts[0] = full;
+    variants[1] = small(rem); counts[1] = rem;
+    return 2;
+}
+extern "C" int tx_plan_blind_rotate(size_t count, int num_cus, int *variants, size_t *counts)
+{
+    if (!variants || !counts || num_cus <= 0) return fail("tx_plan_blind_rotate: bad argument");
+    return br_plan(count, num_cus, -1, variants, counts);
+}
+
 static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, uint64_t *acc)
 {
     const int n = (int)c->p.n;
@@ -444,15 +465,13 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
     // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
     // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).
-    if (count == 0) return;
-    const size_t cus = (size_t)c->num_cus;
-    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 0; };
-    if (c->br_variant >= 0) { launch_br(c, c->br_variant, in, count, acc); return; }
-    if (count <= 4 * cus) { launch_br(c, small(count), in, count, acc); return; }
-    const size_t pass = 8 * cus, rem = count % pass, full = count - rem;
-    if (full == 0 || rem == 0 || rem > 4 * cus) { launch_br(c, 5, in, count, acc); return; }
-    launch_br(c, 5, in, full, acc);
-    launch_br(c, small(rem), in + full * (c->p.n + 1), rem, acc + full * GL);
+    size_t counts[2]; int variants[2];
+    const int n_launch = br_plan(count, c->num_cus, c->br_variant, variants, counts);
+    size_t done = 0;
+    for (int i = 0; i < n_launch; i++) {
+        launch_br(c, variants[i], in + done * (c->p.n + 1), counts[i], acc + done * GL);
+        done += counts[i];
+    }
 }
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {

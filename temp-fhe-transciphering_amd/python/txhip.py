@@ -38,7 +38,7 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
            "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles",
-           "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns"]
+           "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns", "tx_plan_blind_rotate"]
 
 _LIB = None
 
@@ -73,6 +73,7 @@ def lib():
         L.tx_get_timing.argtypes = [C.c_void_p, C.POINTER(TxTiming)]
         L.tx_get_twiddles.argtypes = [C.c_void_p, f64p]
         L.tx_ctr_shared_columns.argtypes = [u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.tx_plan_blind_rotate.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         L.tx_last_blind_rotate_kernel.restype = C.c_char_p
         L.tx_last_blind_rotate_kernel.argtypes = [C.c_void_p]
         _LIB = L
@@ -89,6 +90,15 @@ def aes_tight(n=768):
     lib().tx_params_aes_tight(C.byref(p))
     p.n = n
     return p
+
+
+def plan_blind_rotate(count, num_cus=256):
+    """[(kernel number, units), ...]: the launches run_br splits a blind rotation of `count` units into (host logic, no GPU)"""
+    v = (C.c_int * 2)(); n = (C.c_size_t * 2)()
+    k = lib().tx_plan_blind_rotate(count, num_cus, v, n)
+    if k < 0:
+        raise TxError(lib().tx_last_error().decode())
+    return [(int(v[i]), int(n[i])) for i in range(k)]
 
 
 def ctr_shared_columns(iv, first_block, n_blocks):
