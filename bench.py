@@ -7,8 +7,13 @@ linear layer]) over the
 medium instance's 64 AES blocks, sharded block-wise over the ranks (one process per GPU), keys and
 ciphertext bytes resident, result LWEs left in HBM and (N > 1) gathered to rank 0 with one RCCL
 gather.  Prints ONE JSON line on rank 0.
+
+`python bench.py --gpus N` is a complete N-rank run: started without RANK in the environment it launches its own N
+rank processes (before this process has made any GPU call), forwards rank 0's line and exits with the ranks' status;
+started under `python -m torch.distributed.run` (RANK set) it is one of the ranks.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,30 +25,45 @@ sys.path.insert(0, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 
-# HBM-side traffic of ONE blind-rotation launch over 8192 units (medium on one GPU), from separate rocprofv3 --pmc
-# passes: FETCH_SIZE x 2 (gfx950 counts half of a 16 B/lane streaming read, MI355X_MICROARCH.md HBM) + WRITE_SIZE.
-# The key stream (54 MiB of Fourier keys) is re-read once per XCD per resident batch of waves, mostly from the
-# Infinity Cache.  k_blind_rotate5 (two waves per SIMD, persistent; runs above 4 units per CU):
-# profiles/r2_final_pmc_{fetch,write}_size_blind_rotate5.csv (each XCD streams the key 4 times, once per unit of a wave);
-# k_blind_rotate4: profiles/r2_pmc_{fetch,write}_size_blind_rotate4.csv; k_blind_rotate: profiles/r1_pmc_{fetch,write}_size_br_trace.csv.
-# The default command (medium, CTR, shared columns): its nine k_blind_rotate5 launches per step are eight of 8192 units and
-# one of 2048 (the second round's distinct columns; the 96 units of its ragged tail go to k_blind_rotate6).  Average per
-# launch over exactly those launches, separate --pmc passes over `bench.py --steps 1` (tools/profile_round.sh):
-# profiles/r3g_pmc_{fetch,write}_size_bench_command.csv: FETCH_SIZE 852 378 KiB (x 2), WRITE_SIZE 191 488 KiB.
-BR_TRAFFIC_AVG_DEFAULT_MIX = (852378 * 2 + 191488) * 1024
-BR_TRAFFIC_BYTES_8192 = {"k_blind_rotate5": (930104 * 2 + 207872) * 1024, "k_blind_rotate4": (1779967 * 2 + 196608) * 1024,
-                         "k_blind_rotate": (1795972 * 2 + 196608) * 1024}
-# PMC pass over the same launch (tools/pmc_kernel.sh, profiles/r2c_pmc_sq_blind_rotate5.csv): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
-# = 0.401 per wave, two waves per SIMD
-BR_VALU_BUSY_PMC = {"k_blind_rotate5": 0.80}
+# Counter-derived figures of the dominant kernel (HBM-side traffic per launch from separate rocprofv3 --pmc passes, FETCH_SIZE x 2
+# + WRITE_SIZE per MI355X_MICROARCH.md's gfx950 correction; vector-pipe occupancy from an SQ pass) are NOT constants of this
+# file: profiles/roofline_inputs.json names, for each figure, the CSV under profiles/ it was read from and the sha256 of the
+# generated instruction stream (csrc/tx_br_asm_fair.inc) it was measured on.  A figure whose hash is not that of the stream
+# in this tree is reported as null, never as a stale number.
+ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+BR_STREAM = os.path.join(ROOT, "temp-fhe-transciphering_amd", "csrc", "tx_br_asm_fair.inc")
 # per wave and CMux step: v_add_f64 + v_mul_f64 + 2 x v_fma_f64 (`tools/asmgen/brgen.py --count` for the generated loop:
 # 984 + 312 + 2 x 744 = 2784 flops in 2040 FP64 instructions; the same arithmetic in the hipcc kernels)
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (984 + 312 + 2 * 744)
 
 
+def roofline_inputs(path=ROOFLINE_INPUTS, stream=BR_STREAM):
+    """{key: entry} of profiles/roofline_inputs.json whose recorded sha256 is that of the instruction stream in this tree"""
+    try:
+        doc = json.load(open(path))
+        have = hashlib.sha256(open(stream, "rb").read()).hexdigest()
+    except (OSError, ValueError):
+        return {}
+    return {k: e for k, e in doc.get("entries", {}).items() if e.get("stream_sha256") == have}
+
+
 def algorithmic_bytes_per_block(M):
     """stage-materialised model, keys once per stage per batch of M blocks"""
     return 1.847e9 + 0.556e9 / M
+
+
+# SURVEY.md 8(d), per block and FULL bootstrapped round: KS 2.89 + blind rotation 3.93 + extract/trace 25.17 + scheme switch 88.08 +
+# LUT tree 74.45 MB scale with the units (bit ciphertexts) a round actually bootstraps; the linear layer's 10.49 MB does not
+BOOTSTRAP_BYTES_PER_BLOCK_ROUND = (2.89 + 3.93 + 25.17 + 88.08 + 74.45) * 1e6
+
+
+def path_algorithmic_bytes(n_blocks, units_bootstrapped, launches_of_the_keys=1):
+    """algorithmic bytes of ONE pass over n_blocks blocks in which the blind rotations processed units_bootstrapped units in
+    total (tx_timing.units_blind_rotate): the full model 9 x 128 units per block, minus the per-round terms of the units the
+    schedule did not materialise (CTR: the shared second round bootstraps each distinct column once), keys once per batch"""
+    full_units = 9 * 128 * n_blocks
+    skipped_block_rounds = max(0, full_units - units_bootstrapped) / 128.0
+    return n_blocks * 1.847e9 + launches_of_the_keys * 0.556e9 - skipped_block_rounds * BOOTSTRAP_BYTES_PER_BLOCK_ROUND
 
 
 def br_launch_bytes(units, n, launches=1):
@@ -81,7 +101,7 @@ def cpu_baseline(n, seed, threads):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -95,17 +115,111 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: --blocks in total (the medium instance); weak: --blocks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-unshared-leg", action="store_true",
-                    help="CTR mode, one GPU: after the timed region also time the same instance with every column of the second "
-                         "round evaluated, compare the two results on the device and report that rate as "
-                         "ctr_shared_columns.value_without_sharing (off by default: its launches would enter a profiler's "
-                         "per-kernel averages of this command)")
+    ap.add_argument("--no-equal-work-legs", "--no-unshared-leg", dest="no_equal_work_legs", action="store_true",
+                    help="one GPU, CTR: skip the two legs that follow the timed region by default -- the same instance with every "
+                         "column of the second round evaluated (value_without_sharing; outputs compared with the shared "
+                         "schedule's on the device) and under the reference's own ECB inverse-cipher schedule "
+                         "(value_ecb_schedule).  Profiler scripts pass this: the legs' launches would enter the per-kernel "
+                         "averages of the command")
     ap.add_argument("--no-ctr-share", action="store_true",
                     help="CTR mode: bootstrap every state column of the second round, also those that hold the same ciphertexts "
                          "in every block of the batch (TX_CTR_SHARE=0; same results, for A/B timing)")
+    ap.add_argument("--with-mini-workloads", action="store_true",
+                    help="after the timed region run the two post-transcipher mini-workloads (max, inner product mod 2^16) on the "
+                         "result LWEs where they lie in HBM (tx_max_u16_io / tx_inner_product_u16_io, device in, device out), "
+                         "verify both against the cleartext and report their seconds beside `value`")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
-    args = ap.parse_args()
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 still goes through init_process_group and the collectives of the sharded path (one RCCL gather "
+                         "of the result LWEs; with --with-mini-workloads the gathers of max / inner product)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / shard / gather logic only: no GPU, no engine, row patterns instead of ciphertexts "
+                         "(CPU rehearsal of the N-rank launch with --backend gloo)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` started as a plain command (no RANK): the N ranks as fresh child processes (txdist.launch_ranks:
+    before any GPU call in this process, no process replaced, fail-fast on a node with fewer GPUs)"""
+    import txdist
+
+    def prepare():
+        import __graft_entry__
+        __graft_entry__.build()                  # once, in the parent: the ranks then find the libraries up to date
+    return txdist.launch_ranks(__file__, argv, args.gpus, backend=args.backend, need_gpu=not args.dry_run,
+                               prepare=None if args.dry_run else prepare, name="bench.py")
+
+
+def dry_run(args, rank, world):
+    """The launch path without a GPU: rendezvous, block sharding, the gather of the result rows and the max-over-ranks
+    reduction of the timed region, with row patterns (global block number, bit index) in place of ciphertexts."""
+    import torch
+    import txdist
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    n_blocks = args.blocks * (world if args.scaling == "weak" else 1)
+    ct = bytes(16 * n_blocks)
+    seen = {}
+
+    def local_fn(ct_slab, iv_slab, n_local, n_pad):
+        start, _ = txdist.shard(n_blocks, world, rank)
+        out = torch.full((n_pad * 128, 4), -1, dtype=torch.int64)
+        for b in range(n_local):
+            out[b * 128:(b + 1) * 128, 0] = start + b
+            out[b * 128:(b + 1) * 128, 1] = torch.arange(128)
+        out[:, 2] = rank
+        seen["n"] = n_local
+        return out
+
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        res = txdist.transcipher_sharded(local_fn, ct, None, rank, world, dist)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ok = True
+    if rank == 0:
+        want_blocks = torch.arange(n_blocks).repeat_interleave(128)
+        ok = (res.shape[0] == n_blocks * 128 and bool(torch.equal(res[:, 0], want_blocks))
+              and bool(torch.equal(res[:, 1], torch.arange(128).repeat(n_blocks))))
+        ranks = sorted(set(int(v) for v in res[:, 2].tolist()))
+        print(json.dumps({"metric": "AES blocks transciphered/sec (medium instance)", "value": None, "unit": "AES blocks/s",
+                          "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": args.backend,
+                          "blocks": n_blocks, "blocks_per_rank": [txdist.shard(n_blocks, world, r)[1] for r in range(world)],
+                          "ranks_in_result": ranks, "gathered_in_block_order": ok, "scaling": args.scaling}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != world:
+        raise SystemExit(f"bench.py: --gpus {world} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if rank >= world:
+        raise SystemExit(f"bench.py: RANK={rank} outside --gpus {world}")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import txdist as _t
+            os.environ["MASTER_PORT"] = str(_t.free_port()) if world == 1 else "29511"
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
 
     if args.no_ctr_share:
         os.environ["TX_CTR_SHARE"] = "0"             # read once by tx_create
@@ -117,21 +231,19 @@ def main():
     import txclient
     import txdist
 
-    world = args.gpus
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs on this node, it has {torch.cuda.device_count()}")
     # one rank per GPU; a rehearsal with more ranks than GPUs (gloo only) wraps around
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    on_device = args.backend == "nccl"           # RCCL moves device buffers; the gloo rehearsal stages them through the host
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -162,7 +274,7 @@ def main():
     t_load = time.time() - t0
 
     words = 2 * 1024 + 1
-    br_ms, br_launches, br_units = [0.0], [0], [0]
+    br_ms, br_launches, br_units, all_units = [0.0], [0], [0], [0]
 
     out_bufs = {}
 
@@ -177,7 +289,8 @@ def main():
             tm = eng.timing()
             # the blind-rotation kernel that took most units (a call may split a ragged tail off to a small-launch kernel)
             br_ms[0] += tm["ms_br_main"]; br_launches[0] += tm["n_br_main"]; br_units[0] += tm["units_br_main"]
-        return out
+            all_units[0] += tm["units_blind_rotate"]
+        return out if (on_device or dist is None) else out.cpu()
 
     def step():
         return txdist.transcipher_sharded(local_fn, ct, iv, rank, world, dist)
@@ -197,7 +310,7 @@ def main():
     del res
     for _ in range(max(0, args.warmup - 1)):
         step()
-    br_ms[0], br_launches[0], br_units[0] = 0.0, 0, 0
+    br_ms[0], br_launches[0], br_units[0], all_units[0] = 0.0, 0, 0, 0
     last_timing = None
     barrier()
     t0 = time.perf_counter()
@@ -207,34 +320,81 @@ def main():
     dt = time.perf_counter() - t0
     last_timing = eng.timing()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if on_device else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    t_ms, t_launches, t_units = br_ms[0], br_launches[0], br_units[0]      # blind-rotation totals of the timed region
-    # the same instance with every column of the CTR schedule's second round evaluated (no sharing): reported beside `value`
-    value_unshared = None
-    if world == 1 and args.mode == "ctr" and not args.no_ctr_share and args.with_unshared_leg:
+    t_ms, t_launches, t_units, t_all_units = br_ms[0], br_launches[0], br_units[0], all_units[0]   # totals of the timed region
+    _, m_local = txdist.shard(n_blocks, world, rank)
+
+    # ---- equal-work legs (one GPU, CTR): the same instance with every column of the second round evaluated, and under the
+    # reference's own ECB inverse-cipher schedule (server_encrypted_aes_decryption.rs:130-180) -- one warm-up + two timed steps each
+    value_unshared = value_ecb = None
+    if world == 1 and args.mode == "ctr" and not args.no_ctr_share and not args.no_equal_work_legs:
         os.environ["TX_CTR_SHARE"] = "0"
         eng2 = txhip.Engine(p, device=dev_index)
         del os.environ["TX_CTR_SHARE"]
         eng2.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
         eng2.load_ctr_luts(luts)
         out2 = torch.empty((n_blocks * 128, words), dtype=torch.int64, device=dev)
-        eng2.transcipher(ct, iv, out_device_ptr=out2.data_ptr())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            eng2.transcipher(ct, iv, out_device_ptr=out2.data_ptr())
-        torch.cuda.synchronize()
-        value_unshared = n_blocks * 2 / (time.perf_counter() - t0)
-        same = bool(torch.equal(out2, step()))            # the two schedules give the same ciphertexts, bit for bit
-        eng2.close()
-        if not same:
+
+        def leg(ct_, iv_):
+            eng2.transcipher(ct_, iv_, out_device_ptr=out2.data_ptr())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                eng2.transcipher(ct_, iv_, out_device_ptr=out2.data_ptr())
+            torch.cuda.synchronize()
+            return n_blocks * 2 / (time.perf_counter() - t1)
+
+        value_unshared = leg(ct, iv)
+        shared = out_bufs[m_local]
+        eng.transcipher(ct, iv, out_device_ptr=shared.data_ptr())
+        if not bool(torch.equal(out2, shared)):               # the two schedules give the same ciphertexts, bit for bit
             raise SystemExit("bench.py: shared and unshared CTR schedules differ; no number reported")
+        eng2.load_round_luts(keys.round_luts(aes_key, seed=args.seed + 2))
+        value_ecb = leg(txclient.aes_ecb_encrypt(aes_key, pt), None)
+        if not np.array_equal(txclient.bits_to_u16(keys.decrypt_bits(out2.cpu().numpy().view(np.uint64))), db):
+            raise SystemExit("bench.py: the ECB schedule's result does not decrypt to the plaintext; no number reported")
+        eng2.close()
+        del out2
+
+    # ---- the two post-transcipher mini-workloads on the device-resident result (config 5 of BASELINE.json at --blocks 512)
+    mini = None
+    if args.with_mini_workloads:
+        mine = out_bufs[-(-n_blocks // world)]
+        n_local_values, n_values = m_local * 8, n_blocks * 8
+        cdev = dev if (on_device or dist is None) else torch.device("cpu")
+
+        def on_card(fn):
+            def run(t):
+                t = t.to(dev).contiguous()
+                o = torch.empty((16, words), dtype=torch.int64, device=dev)
+                fn(t.data_ptr(), t.shape[0] // 16, o.data_ptr())
+                return o.to(cdev)
+            return run
+
+        mine_c = mine if cdev == dev else mine.cpu()
+        barrier(); t1 = time.perf_counter()
+        mx = txdist.max_sharded(on_card(eng.max_u16_device), mine_c, n_local_values, rank, world, dist)
+        barrier(); t_max = time.perf_counter() - t1
+        ranges = [(8 * s, 8 * c) for s, c in (txdist.shard(n_blocks, world, r) for r in range(world))]
+        t1 = time.perf_counter()
+        ip = txdist.inner_product_sharded(on_card(eng.inner_product_u16_device), mine_c[: n_local_values * 16], ranges, n_values,
+                                          rank, world, dist)
+        barrier(); t_ip = time.perf_counter() - t1
+        if rank == 0:
+            vals = [int(v) for v in db]
+            half = len(vals) // 2
+            got_max = int(txclient.bits_to_u16(keys.decrypt_bits(mx.cpu().numpy().view(np.uint64)))[0])
+            got_ip = int(txclient.bits_to_u16(keys.decrypt_bits(ip.cpu().numpy().view(np.uint64)))[0])
+            exp_ip = sum((vals[i] * vals[i + half]) % 65536 for i in range(half)) % 65536
+            if got_max != max(vals) or got_ip != exp_ip:
+                raise SystemExit("bench.py: a mini-workload result does not decrypt to the cleartext value; no number reported")
+            mini = {"values": n_values, "max_s": t_max, "inner_product_s": t_ip, "verified": True,
+                    "input": "result LWEs of the transcipher, device-resident (tx_max_u16_io / tx_inner_product_u16_io, in_is_device = 1)"}
 
     if rank == 0:
-        _, m_local = txdist.shard(n_blocks, world, 0)
         value = n_blocks * args.steps / dt
         br_avg_ms = t_ms / max(1, t_launches)
         br_avg_units = t_units / max(1, t_launches)
@@ -243,7 +403,16 @@ def main():
         # only the distinct state columns): algorithmic bytes of all of them over the time of all of them
         achieved = br_launch_bytes(t_units, args.n, t_launches) / (t_ms * 1e-3) / 1e9
         br_flops = t_units * args.n * BR_F64_FLOP_PER_UNIT_STEP
-        default_mix = (m_local == 64 and args.n == 768 and args.mode == "ctr" and not args.no_ctr_share and br_kernel == "k_blind_rotate5")
+        # counter-derived figures: only from profiles/roofline_inputs.json, only when measured on this tree's instruction stream
+        # and on this launch mix (the entry states the average units per launch its CSV covers)
+        rin = roofline_inputs() if (args.n == 768 and br_kernel == "k_blind_rotate5") else {}
+        def counter(key):
+            e = rin.get(key)
+            return e if (e and abs(e.get("avg_units_per_launch", -1) - br_avg_units) < 0.5) else None
+        tr, vb = counter("traffic_default_mix") or counter("traffic_8192_units"), counter("vector_pipe_busy")
+        units_step = t_all_units / args.steps              # units this rank's blind rotations processed per step
+        path_bytes = path_algorithmic_bytes(m_local, units_step)
+        path_gbps = path_bytes / (dt / args.steps) / 1e9
         line = {
             "metric": "AES blocks transciphered/sec (medium instance)", "value": value, "unit": "AES blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -251,32 +420,41 @@ def main():
             "config": {"workload": f"medium instance: {n_blocks} AES-128 blocks (512 x u16 per 64 blocks), "
                                    f"AES_TIGHT n={args.n}, {'ECB inverse-cipher schedule of the reference' if args.mode == 'ecb' else 'CTR forward-cipher schedule'}, "
                                    f"full 10 rounds, keys resident, result LWEs left in HBM",
-                       "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather"},
+                       "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather",
+                       "backend": (args.backend if dist is not None else None)},
+            "value_without_sharing": value_unshared, "value_ecb_schedule": value_ecb,
             "roofline": {"bound": "hbm", "kernel": br_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (BR_TRAFFIC_AVG_DEFAULT_MIX if default_mix else
-                                     (BR_TRAFFIC_BYTES_8192.get(br_kernel) if abs(br_avg_units - 8192) < 0.5 and args.n == 768 else None)),
+                         "traffic": (tr["bytes_per_launch"] if tr else None),
+                         "traffic_source": (tr["source"] if tr else None),
                          "avg_launch_ms": br_avg_ms, "launches": t_launches, "avg_units_per_launch": br_avg_units,
                          "algorithmic_bytes_per_launch": br_launch_bytes(t_units, args.n, t_launches) / max(1, t_launches),
-                         "path_algorithmic_GBps": value / world * algorithmic_bytes_per_block(m_local) / 1e9,
-                         "path_frac": value / world * algorithmic_bytes_per_block(m_local) / 1e9 / HBM_PEAK_GBS,
+                         "units_bootstrapped_per_step": units_step, "units_of_the_full_schedule": 9 * 128 * m_local,
+                         "path_algorithmic_bytes_per_step": path_bytes,
+                         "path_algorithmic_GBps": path_gbps, "path_frac": path_gbps / HBM_PEAK_GBS,
                          "fp64_valu": {"achieved_TFLOPs": br_flops / (t_ms * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
                                        "frac": br_flops / (t_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-                         "vector_pipe_busy_pmc": (BR_VALU_BUSY_PMC.get(br_kernel) if (m_local * 128 == 8192 and args.n == 768) else None),
+                         "vector_pipe_busy_pmc": (vb["value"] if vb else None),
+                         "vector_pipe_busy_source": (vb["source"] if vb else None),
                          "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
+                                 "path_* = SURVEY 8(d)'s stage-materialised bytes of the units this step actually bootstrapped "
+                                 "(the CTR schedule's shared second round materialises fewer) over the step time; "
                                  "fp64_valu counts FP64 flops against the FMA peak at the nominal clock (half of this loop's FP64 "
                                  "instructions are adds, a fifth of its vector instructions 32-bit, and the chip runs it at "
                                  "1.85-1.9 GHz: power-bound); vector_pipe_busy_pmc is the fraction of cycles a SIMD's vector pipe "
-                                 "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES, "
-                                 "profiles/r2c_pmc_sq_blind_rotate5.csv)"},
+                                 "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES); traffic and "
+                                 "vector_pipe_busy_pmc come from profiles/roofline_inputs.json and are null unless they were "
+                                 "measured on this tree's instruction stream and this launch mix"},
             "ctr_shared_columns": (None if args.mode != "ctr" else
                                    {"enabled": not args.no_ctr_share, "value_without_sharing": value_unshared,
                                     "note": "CTR: the state entering the second round is a public function of the counters, so columns fed by "
                                             "the same counter bytes hold the same ciphertexts in every block; each distinct column is "
                                             "bootstrapped once (64 consecutive counters: 268 of 1024 bytes in that round, the other 8 "
-                                            "rounds in full); outputs identical to evaluating every column (--no-ctr-share does; "
-                                            "--with-unshared-leg times and compares both in one run: 130.0 against 120.4 blocks/s, "
-                                            "profiles/r3m_bench_line_with_unshared_leg.json)"}),
+                                            "rounds in full); outputs identical to evaluating every column (value_without_sharing: "
+                                            "timed after the timed region on a second context with TX_CTR_SHARE=0, outputs compared on "
+                                            "the device; value_ecb_schedule: the reference's own inverse-cipher schedule, every column "
+                                            "in every round)"}),
+            "mini_workloads": mini,
             "kernel_ms_last_step": {k: round(v, 3) for k, v in last_timing.items() if k.startswith("ms_")},
             "setup_s": {"client_keygen": round(t_keygen, 2), "key_upload_and_transform": round(t_load, 3)},
         }
@@ -286,6 +464,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.n, args.seed, max(1, min(avail, 16)))
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     eng.close()
 

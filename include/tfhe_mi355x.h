@@ -102,6 +102,11 @@ int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks,
  * values given as n_values*16 LWE bits, MSB first); log-depth tournament.
  * out: 16 LWE ciphertexts. */
 int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe);
+/* The same with the location of each buffer stated (mirrors out_is_device of tx_transcipher): in_is_device != 0: lwe_bits is
+ * device memory on the context's GPU, e.g. what tx_transcipher(.., out_is_device = 1) left there -- the reference's compute
+ * stage consumes what the transciphering stage left behind (server_encrypted_compute.rs:203-263), here without a round trip
+ * through host memory; the input is only read.  out_is_device != 0: the 16 result LWEs are written to device memory. */
+int tx_max_u16_io(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device, int out_is_device);
 
 /* Mini-workload 1 of the harness (harness/cleartext_impl.py:65-70; the reference has no server
  * implementation of it): sum over i < n/2 of (v[i] * v[i + n/2] mod 2^16), mod 2^16, for n_values
@@ -110,6 +115,9 @@ int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *o
  * (carry = (a^b) ? c : a, sum = (a^b) ? !c : c, one circuit bootstrap of a^b per adder), final
  * ripple-carry row.  out: 16 LWE ciphertexts, MSB first. */
 int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe);
+/* with device-resident input and / or output, as tx_max_u16_io */
+int tx_inner_product_u16_io(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device,
+                            int out_is_device);
 
 /* ---- stage-level entry points (one per row of SURVEY.md section 8a), host pointers ---- */
 /* a4 keyswitch_lwe_ciphertext_by_glwe_keyswitch (fourier_glwe_keyswitch.rs:344-379) */
@@ -121,6 +129,12 @@ int tx_stage_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_
 /* a8+a9 switch_scheme + convert_standard_ggsw_ciphertext_to_fourier (ggsw_conv.rs:163-193,
  * SRV_AES:430-436); output is the private Fourier layout, count*cbs_level*K*K*N doubles */
 int tx_stage_scheme_switch_fourier(tx_ctx *c, const uint64_t *glev, size_t count, double *ggsw_f);
+/* a4-a9 in one call, as the round pipeline runs them: circuit_bootstrap of `count` big LWEs
+ * (lwe_msb_bit_to_glev_by_trace_with_preprocessing + switch_scheme + GGSW->Fourier, ggsw_conv.rs:231-318, 163-193;
+ * SRV_AES:350-436): key switch, blind rotation (kernel by launch size), then extraction, trace, scheme switch and forward
+ * transform in the fused persistent kernel the pipeline uses (k_trace_scheme_switch4).  Output as
+ * tx_stage_scheme_switch_fourier: count*cbs_level*K*K*N doubles */
+int tx_stage_circuit_bootstrap(tx_ctx *c, const uint64_t *lwe_big, size_t count, double *ggsw_f);
 /* a10 evaluate_8_to_8_cipher_lut (SRV_AES:550-588) for nlut tables of loaded set `set`
  * (ctr == 0: round tables, nlut = 4 or 1 for set 9; ctr != 0: CTR tables).
  * out[(lut*nbytes + byte)*8 + bit] big LWEs */
@@ -140,7 +154,14 @@ typedef struct {
     uint32_t n_br_main;
     double ms_br_main;
     uint64_t units_br_main;
+    /* units (bit ciphertexts) all blind-rotation launches of the call processed together: the work actually done, e.g.
+     * 8 x 8192 + 2144 for the medium instance under the CTR schedule with its shared second round (round 4) */
+    uint64_t units_blind_rotate;
 } tx_timing;
+/* tx_timing is APPEND-ONLY: fields are only ever added at the end (round 3: n_br_main, ms_br_main, units_br_main; round 4:
+ * units_blind_rotate).  tx_get_timing writes tx_timing_size() bytes: a binding compiled against an older header must
+ * either be rebuilt or check tx_timing_size() against its own sizeof before it calls tx_get_timing. */
+size_t tx_timing_size(void);
 int tx_get_timing(tx_ctx *c, tx_timing *t);
 /* name of the blind-rotation kernel that processed most units of the last call ("k_blind_rotate5", "k_blind_rotate6",
  * "k_blind_rotate", ...; "" before the first call).  The dispatch is by launch size (and the TX_BR_VARIANT experiment

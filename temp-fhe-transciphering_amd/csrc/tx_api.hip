@@ -7,10 +7,12 @@
 #include "tx_kernels.hpp"
 #include "tx_br2.hpp"
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace txd;
@@ -44,6 +46,9 @@ struct tx_ctx {
     int trss_wgs_per_cu = 1;                // TX_TRSS_WGS_PER_CU (experiments)
     int ctr_share = 1;                      // TX_CTR_SHARE=0: the CTR schedule bootstraps every column of its second round, shared or not
     const char *last_br_kernel = "";        // blind-rotation kernel that took most units of the last call (tx_last_blind_rotate_kernel)
+    struct BrUse { const char *kernel; uint64_t units; uint32_t launches; };
+    std::vector<BrUse> br_use;              // launches of the current call by kernel (launch_br; does not depend on the events)
+    const char *ev_error = nullptr;         // first HIP event call that failed during the current call (ev_begin / ev_end)
     uint64_t *share_tmp = nullptr; size_t share_tmp_bits = 0;      // compact LUT output of the CTR schedule's shared round
     int *d_idx = nullptr; uint8_t *d_pos = nullptr; size_t idx_cap = 0;
     uint64_t *luts = nullptr, *ctr_luts = nullptr;
@@ -220,32 +225,44 @@ static size_t ctr_lut_words() { return (size_t)10 * 3 * 16 * 2 * GL; }
 static inline int grid_for(size_t units) { return (int)((units + WAVES - 1) / WAVES); }
 
 // ---- timing helpers: HIP events on the launch stream ----
+// A failed event call never stops a launch sequence half way (the kernels between ev_begin and ev_end still run): it is
+// remembered in c->ev_error, no further events are recorded for the call, and timing_collect fails the call with it.
 static void ev_begin(tx_ctx *c, int fam, const char *kernel = "", size_t units = 0)
 {
-    if (!c->time_enabled) return;
+    if (!c->time_enabled || c->ev_error) return;
     if (c->ev_used == c->ev_pool.size()) {
-        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess) { c->ev_error = "hipEventCreate"; return; }
+        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); c->ev_error = "hipEventCreate"; return; }
         c->ev_pool.push_back({a, b});
     }
     auto &e = c->ev_pool[c->ev_used];
-    hipEventRecord(e.first, c->stream);
+    if (hipEventRecord(e.first, c->stream) != hipSuccess) { c->ev_error = "hipEventRecord"; return; }
     c->evs.push_back({fam, kernel, units, e.first, e.second});
 }
 static void ev_end(tx_ctx *c)
 {
-    if (!c->time_enabled) return;
-    hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    if (!c->time_enabled || c->ev_error) return;
+    if (c->evs.size() != c->ev_used + 1) return;            // the matching ev_begin recorded nothing
+    if (hipEventRecord(c->ev_pool[c->ev_used].second, c->stream) != hipSuccess) { c->ev_error = "hipEventRecord"; c->evs.pop_back(); return; }
     c->ev_used++;
 }
-static void timing_reset(tx_ctx *c) { c->evs.clear(); c->ev_used = 0; memset(&c->timing, 0, sizeof c->timing); }
-static void timing_collect(tx_ctx *c)
+static void timing_reset(tx_ctx *c)
 {
+    c->evs.clear(); c->ev_used = 0; memset(&c->timing, 0, sizeof c->timing);
+    c->br_use.clear(); c->last_br_kernel = ""; c->ev_error = nullptr;
+}
+static int timing_collect(tx_ctx *c)
+{
+    if (c->ev_error) return fail(std::string(c->ev_error) + " failed while timing the call (results were computed; no timing reported)");
+    if (c->evs.size() != c->ev_used) c->evs.resize(c->ev_used);
     double ms[F_COUNT] = {0}; uint32_t cnt[F_COUNT] = {0};
     // the blind rotation by kernel: a call may use more than one (launch-size dispatch, split tails)
     struct G { const char *k; double ms; uint32_t n; uint64_t units; };
     std::vector<G> br;
     for (auto &e : c->evs) {
-        float t = 0; hipEventElapsedTime(&t, e.a, e.b);
+        float t = 0;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return fail("hipEventElapsedTime failed while timing the call");
         ms[e.fam] += t; cnt[e.fam]++;
         if (e.fam == F_BR) {
             size_t g = 0;
@@ -260,10 +277,17 @@ static void timing_collect(tx_ctx *c)
     t.n_keyswitch = cnt[F_KS]; t.n_blind_rotate = cnt[F_BR]; t.n_trace = cnt[F_TRACE];
     t.n_scheme_switch = cnt[F_SS]; t.n_lut_eval = cnt[F_LUT]; t.n_linear = cnt[F_LIN];
     t.ms_total = 0; for (int i = 0; i < F_COUNT; i++) t.ms_total += ms[i];
-    t.ms_br_main = 0; t.n_br_main = 0; t.units_br_main = 0;
+    // what ran is taken from the launches themselves (launch_br), so it is also right in a build without events
+    t.ms_br_main = 0; t.n_br_main = 0; t.units_br_main = 0; t.units_blind_rotate = 0;
+    for (auto &u : c->br_use) {
+        t.units_blind_rotate += u.units;
+        if (u.units > t.units_br_main) { t.units_br_main = u.units; t.n_br_main = u.launches; c->last_br_kernel = u.kernel; }
+    }
     for (auto &g : br)
-        if (g.units > t.units_br_main) { t.units_br_main = g.units; t.ms_br_main = g.ms; t.n_br_main = g.n; c->last_br_kernel = g.k; }
+        if (t.units_br_main && strcmp(g.k, c->last_br_kernel) == 0) t.ms_br_main = g.ms;
+    return 0;
 }
+extern "C" size_t tx_timing_size(void) { return sizeof(tx_timing); }
 extern "C" int tx_get_timing(tx_ctx *c, tx_timing *t) { if (!c || !t) return fail("tx_get_timing: null"); *t = c->timing; return 0; }
 extern "C" const char *tx_last_blind_rotate_kernel(const tx_ctx *c) { return c ? c->last_br_kernel : ""; }
 extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
@@ -423,9 +447,16 @@ extern "C" int tx_plan_blind_rotate(size_t count, int num_cus, int *variants, si
     return br_plan(count, num_cus, -1, variants, counts);
 }
 
+static void br_used(tx_ctx *c, const char *kernel, size_t units)
+{
+    for (auto &u : c->br_use) if (strcmp(u.kernel, kernel) == 0) { u.units += units; u.launches++; return; }
+    c->br_use.push_back({kernel, (uint64_t)units, 1u});
+}
 static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, uint64_t *acc)
 {
     const int n = (int)c->p.n;
+    br_used(c, variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" : variant == 4 ? "k_blind_rotate4" :
+               variant == 3 ? "k_blind_rotate3" : "k_blind_rotate", count);
     if (variant == 6) {
         ev_begin(c, F_BR, "k_blind_rotate6", count);
         hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
@@ -534,15 +565,16 @@ static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return
 // rep_of[b * 4 + col] = index into col_of of the first (block, column) with the same column index and the same four bytes.
 static void ctr_round2_groups(const uint8_t *ctr, size_t nb, std::vector<int> &rep_of, std::vector<int> &col_of)
 {
-    std::vector<std::pair<uint64_t, int>> seen;
+    std::unordered_map<uint64_t, int> seen;                  // (column index, its four counter bytes) -> distinct column
     rep_of.assign(nb * 4, 0); col_of.clear();
     for (size_t b = 0; b < nb; b++)
         for (int col = 0; col < 4; col++) {
             uint64_t key = (uint64_t)col;
             for (int r = 0; r < 4; r++) key = (key << 8) | ctr[b * 16 + 4 * ((r + col) & 3) + r];
-            int idx = -1;
-            for (auto &kv : seen) if (kv.first == key) { idx = kv.second; break; }
-            if (idx < 0) { idx = (int)col_of.size(); seen.push_back({key, idx}); col_of.push_back((int)(b * 4 + col)); }
+            auto it = seen.find(key);
+            int idx;
+            if (it == seen.end()) { idx = (int)col_of.size(); seen.emplace(key, idx); col_of.push_back((int)(b * 4 + col)); }
+            else idx = it->second;
             rep_of[b * 4 + col] = idx;
         }
 }
@@ -558,6 +590,7 @@ static void ctr_blocks(const uint8_t *iv, size_t blk0, size_t nb, std::vector<ui
 extern "C" int tx_ctr_shared_columns(const uint8_t *iv, size_t first_block, size_t n_blocks, int *rep_of, int *col_of)
 {
     if (!iv || !rep_of || !col_of) return fail("tx_ctr_shared_columns: null argument");
+    if (n_blocks > (size_t)INT_MAX / 4) return fail("tx_ctr_shared_columns: n_blocks * 4 does not fit the int indices of rep_of / col_of");
     std::vector<uint8_t> ctr; std::vector<int> rep, cols;
     ctr_blocks(iv, first_block, n_blocks, ctr);
     ctr_round2_groups(ctr.data(), n_blocks, rep, cols);
@@ -702,8 +735,7 @@ static int transcipher_impl(tx_ctx *c, const uint8_t *ct, size_t n_blocks, const
             HIP_OK(hipMemcpyAsync(out + b0 * 128 * BIG, c->res, nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
 
 extern "C" int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv, uint64_t *out_lwe,
@@ -732,8 +764,7 @@ extern "C" int tx_stage_lwe_keyswitch(tx_ctx *c, const uint64_t *lwe_big, size_t
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(lwe_small, out.p, count * sw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
 extern "C" int tx_stage_blind_rotate(tx_ctx *c, const uint64_t *lwe_small, size_t count, uint64_t *acc)
 {
@@ -745,8 +776,7 @@ extern "C" int tx_stage_blind_rotate(tx_ctx *c, const uint64_t *lwe_small, size_
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(acc, out.p, count * GL * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
 extern "C" int tx_stage_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {
@@ -758,8 +788,7 @@ extern "C" int tx_stage_extract_trace(tx_ctx *c, const uint64_t *acc, size_t cou
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(glev, out.p, count * CBS_L * GL * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
 extern "C" int tx_stage_scheme_switch_fourier(tx_ctx *c, const uint64_t *glev, size_t count, double *ggsw_f)
 {
@@ -771,8 +800,29 @@ extern "C" int tx_stage_scheme_switch_fourier(tx_ctx *c, const uint64_t *glev, s
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(ggsw_f, out.p, ow, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
+}
+// a4-a9 as the pipeline runs them (run_cbs: key switch, blind rotation by launch size, then the fused persistent
+// k_trace_scheme_switch4 -- or the separate kernels under TX_TRACE_VARIANT / TX_SS_VARIANT = 0), on host buffers, in chunks of
+// the transcipher's own chunk size (16 384 LWEs)
+extern "C" int tx_stage_circuit_bootstrap(tx_ctx *c, const uint64_t *lwe_big, size_t count, double *ggsw_f)
+{
+    STAGE_PROLOGUE("tx_stage_circuit_bootstrap");
+    if (!lwe_big || !ggsw_f) return fail("tx_stage_circuit_bootstrap: null argument");
+    if (count == 0) return timing_collect(c);
+    const size_t chunk = std::min(count, CHUNK_BLOCKS * 128), gw = (size_t)CBS_L * KP * KP * H * sizeof(cplx);
+    if (ensure_ws(c, (chunk + 127) / 128)) return -1;
+    DevBuf in;
+    if (in.alloc(chunk * BIG * 8)) return fail("hipMalloc failed");
+    for (size_t i0 = 0; i0 < count; i0 += chunk) {
+        const size_t m = std::min(chunk, count - i0);
+        HIP_OK(hipMemcpyAsync(in.p, lwe_big + i0 * BIG, m * BIG * 8, hipMemcpyHostToDevice, c->stream));
+        if (run_cbs(c, (const uint64_t *)in.p, m, c->ggsw_f)) return -1;
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync((char *)ggsw_f + i0 * gw, c->ggsw_f, m * gw, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return timing_collect(c);
 }
 extern "C" int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes, int ctr, int set, int nlut, uint64_t *out)
 {
@@ -788,8 +838,7 @@ extern "C" int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes,
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(out, o.p, ow, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
 
 // ---- a12: max of n_values u16 (SRV_CMP:34-98, 203-351), log-depth tournament ----
@@ -798,7 +847,10 @@ extern "C" int tx_stage_lut_eval(tx_ctx *c, const double *ggsw_f, size_t nbytes,
 // once would need 270 GB).  Chunking only splits batches: every pair sees the same operations in the same order.
 static const size_t MAX_CHUNK_PAIRS = 512;                  // 2 x 512 x 16 bits = 16 384 = CHUNK_BLOCKS x 128
 
-extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+// in_is_device / out_is_device: the pointer is device memory on the context's GPU (what tx_transcipher(.., out_is_device = 1)
+// left there): the tournament then reads the values where they are -- the first level straight from the caller's buffer, which
+// is never written -- and nothing crosses PCIe (SRV_CMP:203-263 consumes what the transciphering stage left behind).
+static int max_impl(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device, int out_is_device)
 {
     if (!c || !lwe_bits || !out_lwe || n_values == 0) return fail("tx_max_u16: bad argument");
     if (!c->have_keys) return fail("tx_max_u16: evaluation keys not loaded");
@@ -806,21 +858,28 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
     timing_reset(c);
     const size_t v16 = (size_t)16 * BIG;
     size_t cnt = n_values;
+    const hipMemcpyKind out_kind = out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (cnt == 1) {                                         // nothing to compare (a rank holding one value in the sharded max)
-        if (out_lwe != lwe_bits) memcpy(out_lwe, lwe_bits, v16 * 8);
-        timing_collect(c);
-        return 0;
+        if (!in_is_device && !out_is_device) { if (out_lwe != lwe_bits) memcpy(out_lwe, lwe_bits, v16 * 8); }
+        else {
+            HIP_OK(hipMemcpyAsync(out_lwe, lwe_bits, v16 * 8, in_is_device ? out_kind : (out_is_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost), c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+        }
+        return timing_collect(c);
     }
     const size_t cp = std::min(cnt / 2, MAX_CHUNK_PAIRS);   // pairs per chunk
     const size_t maxu = cp * 16;                            // cmux units per chunk
     if (ensure_ws(c, (2 * cp * 16 + 127) / 128)) return -1;
     DevBuf cur, nxt, A, B, E, M0, M1, sela, selb;
-    if (cur.alloc(cnt * v16 * 8) || nxt.alloc(((cnt + 1) / 2) * v16 * 8)) return fail("hipMalloc failed");
+    // level buffers: a host input is uploaded into `cur` and the levels alternate between `cur` and `nxt`; a device input is
+    // read in place and the levels alternate between two buffers of half its size
+    if (cur.alloc((in_is_device ? (cnt + 1) / 2 : cnt) * v16 * 8) || nxt.alloc(((cnt + 1) / 2) * v16 * 8)) return fail("hipMalloc failed");
     if (A.alloc(maxu * GL * 8) || B.alloc(maxu * GL * 8) || E.alloc(maxu * GL * 8) || M0.alloc(maxu * GL * 8) ||
         M1.alloc(maxu * GL * 8) || sela.alloc(maxu * 16 * sizeof(int)) || selb.alloc(maxu * 16 * sizeof(int)))
         return fail("hipMalloc failed");
-    HIP_OK(hipMemcpyAsync(cur.p, lwe_bits, cnt * v16 * 8, hipMemcpyHostToDevice, c->stream));
-    uint64_t *pc = (uint64_t *)cur.p, *pn = (uint64_t *)nxt.p;
+    if (!in_is_device) HIP_OK(hipMemcpyAsync(cur.p, lwe_bits, cnt * v16 * 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t *pc = in_is_device ? lwe_bits : (const uint64_t *)cur.p;
+    uint64_t *pn = (uint64_t *)nxt.p, *spare = in_is_device ? (uint64_t *)cur.p : nullptr;
     {   // selector tables, built ONCE for a full chunk: for scan step i (bit index i, MSB-first storage) unit (q, t)
         // selects GGSW (2q) * 16 + i (operand a) or (2q + 1) * 16 + i (operand b) of the chunk.  A chunk with fewer
         // pairs uses the first `units` entries of each step's row: rows are maxu entries apart.
@@ -864,14 +923,22 @@ extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, 
             HIP_OK(hipGetLastError());                      // sticky: also reports a failed copy or launch of the scan above
         }
         if (cnt & 1) HIP_OK(hipMemcpyAsync(pn + all_pairs * v16, pc + (cnt - 1) * v16, v16 * 8, hipMemcpyDeviceToDevice, c->stream));
-        std::swap(pc, pn);                                  // levels are ordered by the stream: no host synchronisation
+        // levels are ordered by the stream: no host synchronisation.  The level just written becomes the input; the next one
+        // goes to the buffer the old input occupied (host input) or to the spare half-size buffer (device input, first level)
+        uint64_t *written = pn;
+        pn = spare ? spare : const_cast<uint64_t *>(pc);
+        spare = nullptr;
+        pc = written;
         cnt = nx;
     }
-    HIP_OK(hipMemcpyAsync(out_lwe, pc, v16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(out_lwe, pc, v16 * 8, out_kind, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
+extern "C" int tx_max_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+{ return max_impl(c, lwe_bits, n_values, out_lwe, 0, 0); }
+extern "C" int tx_max_u16_io(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device, int out_is_device)
+{ return max_impl(c, lwe_bits, n_values, out_lwe, in_is_device, out_is_device); }
 
 // ---- inner product mod 2^16 (harness mini-workload 1), bit-sliced over CMux + circuit bootstrapping ----
 namespace {
@@ -958,7 +1025,7 @@ IpSchedule ip_schedule(int P)
 }
 }  // namespace
 
-extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+static int ip_impl(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device, int out_is_device)
 {
     if (!c || !lwe_bits || !out_lwe || n_values < 2 || (n_values & 1)) return fail("tx_inner_product_u16: need an even number of values");
     if (!c->have_keys) return fail("tx_inner_product_u16: evaluation keys not loaded");
@@ -985,7 +1052,7 @@ extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t 
         dc1.alloc(max_jobs * 4) || df1.alloc(max_jobs * 4) || dout.alloc(max_jobs * 4))
         return fail("hipMalloc failed");
     HIP_OK(hipMemsetAsync(pool.p, 0, (size_t)s.n_slots * BIG * 8, c->stream));
-    HIP_OK(hipMemcpyAsync(pool.p, lwe_bits, n_values * 16 * BIG * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(pool.p, lwe_bits, n_values * 16 * BIG * 8, in_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     std::vector<int> hi0, hi1, hs, h0, hf0, h1, hf1, ho;
     for (auto &L : s.levels) {
         size_t jpos = 0;                                   // jobs are ordered by selector index
@@ -1030,8 +1097,12 @@ extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t 
     }
     for (int k = 0; k < 16; k++)     // MSB first
         HIP_OK(hipMemcpyAsync(out_lwe + (size_t)(15 - k) * BIG, (uint64_t *)pool.p + (size_t)s.result[k] * BIG, BIG * 8,
-                              hipMemcpyDeviceToHost, c->stream));
+                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    timing_collect(c);
-    return 0;
+    return timing_collect(c);
 }
+extern "C" int tx_inner_product_u16(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe)
+{ return ip_impl(c, lwe_bits, n_values, out_lwe, 0, 0); }
+extern "C" int tx_inner_product_u16_io(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_t *out_lwe, int in_is_device,
+                                       int out_is_device)
+{ return ip_impl(c, lwe_bits, n_values, out_lwe, in_is_device, out_is_device); }

@@ -2,8 +2,12 @@
 """One instance of the harness workload block-sharded over the GPUs of one node:
 transcipher + post-transcipher max + inner product, verified on rank 0 against the cleartext.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python temp-fhe-transciphering_amd/python/run_sharded.py <size> --gpus N [--backend nccl|gloo]
+or  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         temp-fhe-transciphering_amd/python/run_sharded.py <size> [--backend nccl|gloo]
+
+(the first form starts its own N rank processes before it has made any GPU call and fails fast on a node with fewer GPUs;
+--force-dist sends a single rank through the process group and every collective as well)
 
 One process per GPU, a full replica of the evaluation keys on each (same FHE seed, no broadcast), contiguous
 slabs of AES blocks per rank; no collective on the data path of the transcipher.  Exchanges: one gather of the
@@ -34,14 +38,24 @@ def main():
     ap.add_argument("--values", type=int, default=0,
                     help="use only the first VALUES u16 of the instance (a multiple of 8 and even): rehearses a per-GPU "
                          "share with fewer ranks than the node has GPUs")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="started as a plain command (no RANK in the environment): launch this many ranks as child processes")
+    ap.add_argument("--force-dist", action="store_true", help="a single rank still initialises the process group and takes every collective")
     args = ap.parse_args()
+
+    import txdist
+    if args.gpus > 1 and "RANK" not in os.environ:
+        def prepare():
+            sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+            import __graft_entry__
+            __graft_entry__.build()
+        sys.exit(txdist.launch_ranks(__file__, sys.argv[1:], args.gpus, backend=args.backend, prepare=prepare, name="run_sharded.py"))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import txhip
     import txclient
-    import txdist
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -51,14 +65,17 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
-    if world > 1:
+    if args.gpus and args.gpus != world:
+        raise SystemExit(f"run_sharded.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("MASTER_PORT", str(txdist.free_port()) if world == 1 else "29513")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    d = dist if world > 1 else None
+    d = dist if use_dist else None
 
     np.random.seed(args.seed)
     db = np.random.randint(0, 65536, size=DB_BOUND[args.size], dtype=np.uint16)
@@ -82,20 +99,28 @@ def main():
         eng.load_round_luts(keys.round_luts(key, seed=args.fhe_seed + 1))
     words = eng.big
 
-    def to_t(a):
-        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(cdev)
-
     def to_np(t):
         return np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
 
     kept = {}
 
     def local_fn(ct_slab, iv_slab, n_local, n_pad):
-        out = torch.zeros((n_pad * 128, words), dtype=torch.int64, device=cdev)
+        # the slab's result LWEs are written to HBM and stay there: the mini-workloads below read them in place
+        # (tx_max_u16_io / tx_inner_product_u16_io, in_is_device = 1); only the gloo rehearsal stages them through the host
+        out = torch.zeros((n_pad * 128, words), dtype=torch.int64, device=dev)
         if n_local:
-            out[: n_local * 128] = to_t(eng.transcipher(ct_slab, iv_slab))
+            eng.transcipher(ct_slab, iv_slab, out_device_ptr=out.data_ptr())
         kept["mine"], kept["n"] = out, n_local
-        return out
+        return out if cdev == dev else out.cpu()
+
+    def on_card(fn):
+        """txdist's local_*_fn over the engine's device entry points: tensor [m * 16, words] in, [16, words] out, on cdev"""
+        def run(t):
+            t = t.to(dev).contiguous()
+            o = torch.empty((16, words), dtype=torch.int64, device=dev)
+            fn(t.data_ptr(), t.shape[0] // 16, o.data_ptr())
+            return o.to(cdev)
+        return run
 
     def sync():
         if d is not None:
@@ -106,16 +131,16 @@ def main():
     sync(); t0 = time.perf_counter()
     res = txdist.transcipher_sharded(local_fn, ct, iv, rank, world, d)
     sync(); t["transcipher_s"] = time.perf_counter() - t0
-    mine, n_local_values = kept["mine"], kept["n"] * 8
+    mine, n_local_values = kept["mine"].to(cdev), kept["n"] * 8
     br_kernel = eng.last_blind_rotate_kernel()             # of this rank's share of the transcipher
 
     t0 = time.perf_counter()
-    mx = txdist.max_sharded(lambda x: to_t(eng.max_u16(to_np(x))), mine, n_local_values, rank, world, d)
+    mx = txdist.max_sharded(on_card(eng.max_u16_device), mine, n_local_values, rank, world, d)
     sync(); t["max_s"] = time.perf_counter() - t0
 
     ranges = [(8 * s, 8 * c) for s, c in (txdist.shard(n_blocks, world, r) for r in range(world))]
     t0 = time.perf_counter()
-    ip = txdist.inner_product_sharded(lambda x: to_t(eng.inner_product_u16(to_np(x))), mine[: n_local_values * 16],
+    ip = txdist.inner_product_sharded(on_card(eng.inner_product_u16_device), mine[: n_local_values * 16],
                                       ranges, n_values, rank, world, d)
     sync(); t["inner_product_s"] = time.perf_counter() - t0
 

@@ -4,8 +4,75 @@ AES blocks are independent (ECB and CTR alike), so rank r processes a contiguous
 its own GPU with a full replica of the evaluation keys; there is NO data-path collective.  The only
 exchange is the final gather of the result LWE ciphertexts (128 x 16392 B per block) to rank 0,
 one `torch.distributed.gather` (RCCL over xGMI on GPUs, gloo in the CPU tests).
+
+`dist` is the initialised `torch.distributed` module, or None for a single process without a process group.  A group
+of ONE rank (bench.py / run_sharded.py --force-dist) goes through every collective below like any other world size.
 """
 import math
+import os
+import socket
+import subprocess
+import sys
+import time
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script, argv, n, backend="nccl", need_gpu=True, prepare=None, name=None):
+    """Start the n ranks of `script argv` as fresh child processes of a parent that was started as a plain command (no RANK in
+    its environment) and return the exit status for the parent.  Nothing here touches the GPU -- importing torch and counting
+    devices does not initialise it -- and no process is replaced: the ranks are ordinary subprocesses (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in their environment), rank 0's output reaches stdout through the
+    inherited descriptor, and the status is the first non-zero status of a rank (the others are then stopped, by PID).
+    Fails fast, with one line, on a node that has fewer GPUs than ranks (nccl: one rank per GPU; gloo rehearsals may share).
+    `prepare` runs once in the parent before the ranks start (building the in-tree libraries)."""
+    name = name or os.path.basename(script)
+    if need_gpu:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            print(f"{name}: no HIP device on this node; there is no CPU fallback for the product path", file=sys.stderr)
+            return 2
+        if backend == "nccl" and ndev < n:
+            print(f"{name}: {n} ranks need {n} GPUs on this node, it has {ndev} "
+                  f"(a rehearsal with several ranks per GPU needs --backend gloo)", file=sys.stderr)
+            return 2
+    if prepare is not None:
+        prepare()
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.1)
+            for p in list(live):
+                r = p.poll()
+                if r is not None:
+                    live.remove(p)
+                    if r != 0:
+                        rc = r
+                        print(f"{name}: rank {procs.index(p)} exited with status {r}; stopping the other ranks", file=sys.stderr)
+                        break
+    finally:
+        for p in procs:                          # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
 
 
 def shard(n_blocks, world, rank):
@@ -28,7 +95,7 @@ def transcipher_sharded(local_fn, ct, iv, rank, world, dist=None, empty_like=Non
     start, cnt = shard(n_blocks, world, rank)
     per = math.ceil(n_blocks / world)
     local = local_fn(ct[16 * start:16 * (start + cnt)], iv_add(iv, start) if iv is not None else None, cnt, per)
-    if world == 1 or dist is None:
+    if dist is None:                       # no process group: one rank (a group of one still takes the collectives)
         return local[: n_blocks * 128]
     import torch
     if rank == 0:
@@ -50,7 +117,7 @@ def max_sharded(local_max_fn, local_lwe_bits, n_local_values, rank, world, dist=
     tournament over the G survivors.  Ranks without values contribute nothing."""
     import torch
     part = local_max_fn(local_lwe_bits[: n_local_values * 16]) if n_local_values > 0 else None
-    if world == 1 or dist is None:
+    if dist is None:                       # no process group: one rank (a group of one still takes the collectives)
         return part
     words = local_lwe_bits.shape[1]
     buf = part if part is not None else torch.zeros((16, words), dtype=local_lwe_bits.dtype, device=local_lwe_bits.device)
@@ -90,7 +157,7 @@ def inner_product_sharded(local_ip_fn, local_lwe_bits, ranges, n_values, rank, w
     half = n_values // 2
     words = local_lwe_bits.shape[1]
     my0, myc = ranges[rank]
-    if world == 1 or dist is None:
+    if dist is None:                       # no process group: one rank (a group of one still takes the collectives)
         return local_ip_fn(local_lwe_bits[: n_values * 16])
 
     def wanted(r):

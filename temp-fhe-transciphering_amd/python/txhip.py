@@ -30,7 +30,7 @@ class TxTiming(C.Structure):
                                           "ms_lut_eval", "ms_linear", "ms_total")] + \
                [(n, C.c_uint32) for n in ("n_keyswitch", "n_blind_rotate", "n_trace", "n_scheme_switch",
                                           "n_lut_eval", "n_linear", "n_br_main")] + \
-               [("ms_br_main", C.c_double), ("units_br_main", C.c_uint64)]
+               [("ms_br_main", C.c_double), ("units_br_main", C.c_uint64), ("units_blind_rotate", C.c_uint64)]
 
 
 EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "tx_load_eval_keys", "tx_eval_key_words",
@@ -38,7 +38,8 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_inner_product_u16",
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
            "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles",
-           "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns", "tx_plan_blind_rotate"]
+           "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns", "tx_plan_blind_rotate",
+           "tx_max_u16_io", "tx_inner_product_u16_io", "tx_stage_circuit_bootstrap", "tx_timing_size"]
 
 _LIB = None
 
@@ -65,6 +66,14 @@ def lib():
         L.tx_transcipher_partial.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_int, u64p]
         L.tx_max_u16.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_inner_product_u16.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.tx_max_u16_io.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        L.tx_inner_product_u16_io.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        L.tx_stage_circuit_bootstrap.argtypes = [C.c_void_p, u64p, C.c_size_t, f64p]
+        L.tx_timing_size.restype = C.c_size_t
+        L.tx_timing_size.argtypes = []
+        if L.tx_timing_size() != C.sizeof(TxTiming):
+            raise TxError("libtfhe_mi355x.so and txhip.py disagree about tx_timing (%d vs %d bytes): rebuild"
+                          % (L.tx_timing_size(), C.sizeof(TxTiming)))
         L.tx_stage_lwe_keyswitch.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_stage_blind_rotate.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
         L.tx_stage_extract_trace.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
@@ -197,7 +206,49 @@ class Engine:
         self._chk(lib().tx_inner_product_u16(self.h, _p64(lwe_bits), nv, _p64(out)))
         return out.reshape(16, self.big)
 
+    def max_u16_device(self, in_device_ptr, n_values, out_device_ptr):
+        """max of n_values u16 whose LWE bits are device memory on this context's GPU; the 16 result LWEs go to device memory"""
+        self._chk(lib().tx_max_u16_io(self.h, C.c_void_p(in_device_ptr), n_values, C.c_void_p(out_device_ptr), 1, 1))
+
+    def inner_product_u16_device(self, in_device_ptr, n_values, out_device_ptr):
+        self._chk(lib().tx_inner_product_u16_io(self.h, C.c_void_p(in_device_ptr), n_values, C.c_void_p(out_device_ptr), 1, 1))
+
+    def max_u16_io(self, lwe_bits_or_ptr, n_values, in_is_device, out_device_ptr=None):
+        """any combination of host / device input and output (tests): a host input is a uint64 array, a host output is returned"""
+        if in_is_device:
+            inp = C.c_void_p(lwe_bits_or_ptr)
+        else:
+            arr = np.ascontiguousarray(lwe_bits_or_ptr, np.uint64)
+            inp = arr.ctypes.data_as(C.c_void_p)
+        if out_device_ptr is not None:
+            self._chk(lib().tx_max_u16_io(self.h, inp, n_values, C.c_void_p(out_device_ptr), int(in_is_device), 1))
+            return None
+        out = np.zeros(16 * self.big, np.uint64)
+        self._chk(lib().tx_max_u16_io(self.h, inp, n_values, out.ctypes.data_as(C.c_void_p), int(in_is_device), 0))
+        return out.reshape(16, self.big)
+
+    def inner_product_u16_io(self, lwe_bits_or_ptr, n_values, in_is_device, out_device_ptr=None):
+        if in_is_device:
+            inp = C.c_void_p(lwe_bits_or_ptr)
+        else:
+            arr = np.ascontiguousarray(lwe_bits_or_ptr, np.uint64)
+            inp = arr.ctypes.data_as(C.c_void_p)
+        if out_device_ptr is not None:
+            self._chk(lib().tx_inner_product_u16_io(self.h, inp, n_values, C.c_void_p(out_device_ptr), int(in_is_device), 1))
+            return None
+        out = np.zeros(16 * self.big, np.uint64)
+        self._chk(lib().tx_inner_product_u16_io(self.h, inp, n_values, out.ctypes.data_as(C.c_void_p), int(in_is_device), 0))
+        return out.reshape(16, self.big)
+
     # ---- stage entry points ----
+    def circuit_bootstrap(self, lwe_big):
+        """a4-a9 as the pipeline runs them (fused trace + scheme switch kernel): Fourier GGSWs [count, level, K, K, N]"""
+        lwe_big = np.ascontiguousarray(lwe_big, np.uint64)
+        cnt = lwe_big.size // self.big
+        out = np.zeros(cnt * self.p.cbs_level * self.K * self.gl, np.float64)
+        self._chk(lib().tx_stage_circuit_bootstrap(self.h, _p64(lwe_big), cnt, _pf(out)))
+        return out.reshape(cnt, self.p.cbs_level, self.K, self.K, self.p.N)
+
     def lwe_keyswitch(self, lwe_big):
         lwe_big = np.ascontiguousarray(lwe_big, np.uint64)
         cnt = lwe_big.size // self.big

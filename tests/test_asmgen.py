@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEN = os.path.join(ROOT, "tools", "asmgen")
 CSRC = os.path.join(ROOT, "temp-fhe-transciphering_amd", "csrc")
@@ -36,6 +38,7 @@ def test_cooperative_loop_equals_oracle_three_waves(oracle):
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.experiments
 def test_paired_loops_equal_oracle_two_waves(oracle):
     """tools/asmgen/brgen2.py (two waves per unit, A = the mask polynomials and columns 0, 1, B = the body and column 2; two
     different programs; an experiment that is NOT in the library -- faster than the one-wave kernel standalone, slower under
@@ -50,6 +53,7 @@ def test_paired_loops_equal_oracle_two_waves(oracle):
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.experiments
 def test_cooperative_trace_experiment_equals_oracle_two_waves(oracle):
     """tools/asmgen/trgen2.py (two waves per unit: A the low-split pass, B the high-split pass, mask polynomials in
     registers; an experiment that is NOT in the library -- it measured slower than the one-wave loop, DESIGN.md section 11 --
@@ -154,10 +158,21 @@ def test_register_budget_and_no_scratch():
     """the generated loops fit 256 VGPRs and issue no scratch instruction (what hipcc keeps around them is bounded by
     test_scratch_of_the_built_kernels): two waves per SIMD is the whole point"""
     sys.path.insert(0, GEN)
-    import brgen, brgen2, brgen3, trgen, trgen2, ssgen, gcn
-    for prog, budget in ((brgen.Gen().build(), 256), (trgen.TraceGen().build(), 256), (ssgen.SsGen().build(), 256),
-                         (brgen3.CoopGen().build(), 168), (trgen2.Trace2Gen().build(), 256),
-                         (brgen2.PairGen("A").build(), 256), (brgen2.PairGen("B").build(), 192)):
+    import brgen, brgen3, trgen, ssgen
+    _check_budget([(brgen.Gen().build(), 256), (trgen.TraceGen().build(), 256), (ssgen.SsGen().build(), 256),
+                   (brgen3.CoopGen().build(), 168)])
+
+
+@pytest.mark.experiments
+def test_register_budget_of_the_experiments():
+    sys.path.insert(0, GEN)
+    import brgen2, trgen2
+    _check_budget([(trgen2.Trace2Gen().build(), 256), (brgen2.PairGen("A").build(), 256), (brgen2.PairGen("B").build(), 192)])
+
+
+def _check_budget(progs):
+    import gcn
+    for prog, budget in progs:
         top = 0
         for i in prog.ins:
             for x in i.a:

@@ -650,3 +650,108 @@ def test_large_instance_properties(rig768):
     mx = r.eng.max_u16(out[:16 * 64])
     mbits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, mx)
     assert int("".join(str(int(b)) for b in mbits), 2) == int(db[:64].max())
+
+
+def test_circuit_bootstrap_fused_kernel_at_depth(rig256, monkeypatch):
+    """a4-a9 through the kernel the pipeline runs them in -- the persistent fused k_trace_scheme_switch4 (ggsw_conv.rs:231-318,
+    163-193) -- at depth: 1210 random big LWEs = 8470 (bit, level) units over 256 persistent workgroups of four waves, so every
+    workgroup loops 8-9 times and the last pass is ragged (8470 % 4 = 2; 8470 % 1024 = 278).  Bit-identical to the oracle's
+    circuit_bootstrap on a 64-LWE sample spread over the first, middle and last groups, and to the separate-kernel path
+    (TX_TRACE_VARIANT=0 / TX_SS_VARIANT=0: hipcc k_extract_trace + k_scheme_switch through a GLev buffer in HBM) on ALL of them"""
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(101)
+    cnt = 1210
+    lwe = rng.integers(0, 1 << 63, (cnt, r.eng.big), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.eng.big), dtype=np.uint64)
+    fused = r.eng.circuit_bootstrap(lwe)
+    tm = r.eng.timing()
+    assert tm["n_trace"] == 1 and tm["n_scheme_switch"] == 0          # one fused launch, no separate scheme switch
+    assert np.array_equal(r.eng.circuit_bootstrap(lwe).view(np.uint64), fused.view(np.uint64))   # a race would not repeat
+    pick = np.r_[0:24, 593:609, cnt - 24:cnt]
+    want = r.octx.circuit_bootstrap(lwe[pick])
+    assert np.array_equal(fused[pick].reshape(len(pick), -1).view(np.uint64), np.asarray(want).reshape(len(pick), -1).view(np.uint64))
+    monkeypatch.setenv("TX_TRACE_VARIANT", "0")
+    monkeypatch.setenv("TX_SS_VARIANT", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    sep = e0.circuit_bootstrap(lwe)
+    t0 = e0.timing()
+    e0.close()
+    assert t0["n_trace"] == 1 and t0["n_scheme_switch"] == 1
+    assert np.array_equal(sep.view(np.uint64), fused.view(np.uint64))
+    # a launch smaller than one persistent pass, and one that is not a multiple of the workgroup's four units
+    assert np.array_equal(r.eng.circuit_bootstrap(lwe[:37]).view(np.uint64), fused[:37].view(np.uint64))
+
+
+def test_mini_workloads_read_device_resident_input(rig256):
+    """tx_max_u16_io / tx_inner_product_u16_io: the result LWEs of a transcipher consumed where they lie in HBM
+    (server_encrypted_compute.rs:203-263 takes what the previous stage left).  Every combination of host / device input and
+    output gives the ciphertexts of the host-pointer entry points, bit for bit; the device input is left untouched; odd counts
+    (the carried value of a tournament level) and the single-value copy included"""
+    import torch
+    r = rig256
+    rng = np.random.default_rng(55)
+    vals = [int(v) for v in rng.integers(0, 65536, 14)]
+    bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+    ct = r.O.lwe_encrypt_bits(r.p, r.keys.glwe_sk, bits, r.p.glwe_std, seed=21)            # [14 * 16, big]
+    d_in = torch.from_numpy(ct.view(np.int64).copy()).cuda()
+    keep = d_in.clone()
+    d_out = torch.zeros((16, r.eng.big), dtype=torch.int64, device="cuda")
+    for nv in (14, 13, 1):
+        want = r.eng.max_u16(ct[: nv * 16])
+        assert np.array_equal(r.eng.max_u16_io(d_in.data_ptr(), nv, True), want)            # device in, host out
+        d_out.zero_()
+        r.eng.max_u16_io(d_in.data_ptr(), nv, True, out_device_ptr=d_out.data_ptr())         # device in, device out
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+        d_out.zero_()
+        r.eng.max_u16_io(ct[: nv * 16], nv, False, out_device_ptr=d_out.data_ptr())          # host in, device out
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+        assert torch.equal(d_in, keep)
+    mbits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, r.eng.max_u16_io(d_in.data_ptr(), 14, True))
+    assert int("".join(str(int(b)) for b in mbits), 2) == max(vals)
+    want = r.eng.inner_product_u16(ct[: 4 * 16])
+    assert np.array_equal(want, r.octx.inner_product_u16(ct[: 4 * 16]))
+    assert np.array_equal(r.eng.inner_product_u16_io(d_in.data_ptr(), 4, True), want)
+    d_out.zero_()
+    r.eng.inner_product_u16_io(d_in.data_ptr(), 4, True, out_device_ptr=d_out.data_ptr())
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+    assert torch.equal(d_in, keep)
+
+
+def test_forced_process_group_of_one_runs_the_rccl_branch():
+    """the `nccl` (= RCCL) branch of the sharded path on the one card there is: `bench.py --gpus 1 --force-dist` and
+    `run_sharded.py --force-dist` initialise the process group with device_id, gather the device-resident result LWEs, take the
+    flag / partial-result gathers of the sharded max and inner product, and reduce the timing over the group"""
+    import subprocess
+    import sys as _sys
+    import json as _json
+    root = os.path.dirname(HERE)
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--blocks", "2", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-equal-work-legs", "--with-mini-workloads"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = _json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["backend"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["mini_workloads"]["verified"] is True and line["mini_workloads"]["values"] == 16
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_sharded.py")
+    r = subprocess.run([_sys.executable, rs, "1", "--force-dist", "--backend", "nccl"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = _json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["checks"] == {"aes": True, "max": True, "inner_product": True} and line["backend"] == "nccl"
+
+
+def test_self_launch_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 8` as a plain command on a node with fewer than eight GPUs: one clear line, non-zero status, and
+    it returns at once instead of waiting for peers that do not exist (the parent has not touched the GPU)"""
+    import subprocess
+    import sys as _sys
+    import time as _time
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node has eight GPUs")
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = _time.time()
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "needs 8 GPUs" in r.stderr and _time.time() - t0 < 120
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

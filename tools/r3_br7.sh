@@ -2,6 +2,13 @@
 # tools/r3_br7.sh <tag>: the paired blind-rotation EXPERIMENT (TX_BR_VARIANT=7; needs a library with tools/asmgen/k_blind_rotate7.hip.txt pasted in, see there) -- parity against the one-wave kernel, then timings
 set -e
 tag=$1
+# This tree does not build the experiment: the library validates TX_BR_VARIANT to 0..6 and has no variant-7 dispatch.  To rerun it,
+# paste tools/asmgen/k_blind_rotate7.hip.txt into csrc/tx_br2.hpp, add the launch_br case and widen the knob range in tx_create
+# (three edits, listed at the top of the .hip.txt), rebuild, and set R3_BR7_BUILT=1.  profiles/r3p_* / r3v_* / r3y_* came from such a build.
+if [ "${R3_BR7_BUILT:-0}" != "1" ]; then
+  echo "tools/r3_br7.sh: the paired blind rotation (variant 7) is not in the library of this tree; see the comment at the top of this script" >&2
+  exit 3
+fi
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
 timeout -k 10 300 python - > $O/${tag}_br7_parity.log 2>&1 <<'PY' || { tail -20 $O/${tag}_br7_parity.log; exit 1; }
 import sys, os
