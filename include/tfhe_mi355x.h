@@ -87,6 +87,15 @@ int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words);
 int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
                    uint64_t *out_lwe, int out_is_device);
 
+/* Device memory on the context's GPU for the `*_is_device` arguments, for a host that has no HIP binding of its own (the
+ * reference's Rust stages): what tx_transcipher(.., out_is_device = 1) writes and tx_max_u16_io / tx_inner_product_u16_io
+ * (.., in_is_device = 1) read.  A pointer from the caller's own hipMalloc / a torch tensor on the same device works as well.
+ * tx_device_alloc returns NULL on failure; the others 0 / negative. */
+void *tx_device_alloc(tx_ctx *c, size_t bytes);
+int   tx_device_free(tx_ctx *c, void *p);
+int   tx_device_upload(tx_ctx *c, void *dst_device, const void *src_host, size_t bytes);
+int   tx_device_download(tx_ctx *c, void *dst_host, const void *src_device, size_t bytes);
+
 /* Host logic of the CTR schedule's shared second round, exposed for tests and tooling (needs no context and no GPU): for the
  * counter blocks iv + first_block + b, b < n_blocks, rep_of[b * 4 + c] is the index (into col_of) of the distinct column that
  * column c of block b equals, col_of[k] = block * 4 + column of the k-th distinct column.  Both arrays hold n_blocks * 4

@@ -316,6 +316,39 @@ extern "C" int tx_debug_stamps(tx_ctx *c, unsigned long long *out16)
 }
 #endif
 
+// ---- device memory for the *_is_device arguments (callers without a HIP binding of their own: the reference's Rust host) ----
+extern "C" void *tx_device_alloc(tx_ctx *c, size_t bytes)
+{
+    if (!c) { fail("tx_device_alloc: null context"); return nullptr; }
+    void *p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+        fail("tx_device_alloc: hipMalloc of " + std::to_string(bytes) + " bytes failed"); return nullptr;
+    }
+    return p;
+}
+extern "C" int tx_device_free(tx_ctx *c, void *p)
+{
+    if (!c) return fail("tx_device_free: null context");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipFree(p));
+    return 0;
+}
+extern "C" int tx_device_upload(tx_ctx *c, void *dst_device, const void *src_host, size_t bytes)
+{
+    if (!c || (bytes && (!dst_device || !src_host))) return fail("tx_device_upload: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int tx_device_download(tx_ctx *c, void *dst_host, const void *src_device, size_t bytes)
+{
+    if (!c || (bytes && (!dst_host || !src_device))) return fail("tx_device_download: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // device buffer released on every exit path
 struct DevBuf {
     void *p = nullptr;

@@ -39,7 +39,8 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_stage_lwe_keyswitch", "tx_stage_blind_rotate", "tx_stage_extract_trace",
            "tx_stage_scheme_switch_fourier", "tx_stage_lut_eval", "tx_get_timing", "tx_get_twiddles",
            "tx_last_blind_rotate_kernel", "tx_ctr_shared_columns", "tx_plan_blind_rotate",
-           "tx_max_u16_io", "tx_inner_product_u16_io", "tx_stage_circuit_bootstrap", "tx_timing_size"]
+           "tx_max_u16_io", "tx_inner_product_u16_io", "tx_stage_circuit_bootstrap", "tx_timing_size",
+           "tx_device_alloc", "tx_device_free", "tx_device_upload", "tx_device_download"]
 
 _LIB = None
 
@@ -69,6 +70,11 @@ def lib():
         L.tx_max_u16_io.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.tx_inner_product_u16_io.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.tx_stage_circuit_bootstrap.argtypes = [C.c_void_p, u64p, C.c_size_t, f64p]
+        L.tx_device_alloc.restype = C.c_void_p
+        L.tx_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        L.tx_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.tx_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.tx_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.tx_timing_size.restype = C.c_size_t
         L.tx_timing_size.argtypes = []
         if L.tx_timing_size() != C.sizeof(TxTiming):
@@ -205,6 +211,25 @@ class Engine:
         out = np.zeros(16 * self.big, np.uint64)
         self._chk(lib().tx_inner_product_u16(self.h, _p64(lwe_bits), nv, _p64(out)))
         return out.reshape(16, self.big)
+
+    # ---- device memory of this context's GPU (no torch needed) ----
+    def device_alloc(self, nbytes):
+        p = lib().tx_device_alloc(self.h, nbytes)
+        if not p:
+            raise TxError(lib().tx_last_error().decode())
+        return p
+
+    def device_free(self, ptr):
+        self._chk(lib().tx_device_free(self.h, C.c_void_p(ptr)))
+
+    def device_upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(lib().tx_device_upload(self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def device_download(self, ptr, shape, dtype=np.uint64):
+        out = np.zeros(shape, dtype)
+        self._chk(lib().tx_device_download(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
 
     def max_u16_device(self, in_device_ptr, n_values, out_device_ptr):
         """max of n_values u16 whose LWE bits are device memory on this context's GPU; the 16 result LWEs go to device memory"""

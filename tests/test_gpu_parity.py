@@ -687,35 +687,49 @@ def test_mini_workloads_read_device_resident_input(rig256):
     """tx_max_u16_io / tx_inner_product_u16_io: the result LWEs of a transcipher consumed where they lie in HBM
     (server_encrypted_compute.rs:203-263 takes what the previous stage left).  Every combination of host / device input and
     output gives the ciphertexts of the host-pointer entry points, bit for bit; the device input is left untouched; odd counts
-    (the carried value of a tournament level) and the single-value copy included"""
-    import torch
-    r = rig256
+    (the carried value of a tournament level) and the single-value copy included.  Device buffers come from the ABI's own
+    tx_device_alloc / upload / download (no torch in this process)"""
+    r, eng = rig256, rig256.eng
     rng = np.random.default_rng(55)
     vals = [int(v) for v in rng.integers(0, 65536, 14)]
     bits = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
     ct = r.O.lwe_encrypt_bits(r.p, r.keys.glwe_sk, bits, r.p.glwe_std, seed=21)            # [14 * 16, big]
-    d_in = torch.from_numpy(ct.view(np.int64).copy()).cuda()
-    keep = d_in.clone()
-    d_out = torch.zeros((16, r.eng.big), dtype=torch.int64, device="cuda")
-    for nv in (14, 13, 1):
-        want = r.eng.max_u16(ct[: nv * 16])
-        assert np.array_equal(r.eng.max_u16_io(d_in.data_ptr(), nv, True), want)            # device in, host out
-        d_out.zero_()
-        r.eng.max_u16_io(d_in.data_ptr(), nv, True, out_device_ptr=d_out.data_ptr())         # device in, device out
-        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
-        d_out.zero_()
-        r.eng.max_u16_io(ct[: nv * 16], nv, False, out_device_ptr=d_out.data_ptr())          # host in, device out
-        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
-        assert torch.equal(d_in, keep)
-    mbits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, r.eng.max_u16_io(d_in.data_ptr(), 14, True))
-    assert int("".join(str(int(b)) for b in mbits), 2) == max(vals)
-    want = r.eng.inner_product_u16(ct[: 4 * 16])
-    assert np.array_equal(want, r.octx.inner_product_u16(ct[: 4 * 16]))
-    assert np.array_equal(r.eng.inner_product_u16_io(d_in.data_ptr(), 4, True), want)
-    d_out.zero_()
-    r.eng.inner_product_u16_io(d_in.data_ptr(), 4, True, out_device_ptr=d_out.data_ptr())
-    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
-    assert torch.equal(d_in, keep)
+    d_in, d_out = eng.device_alloc(ct.nbytes), eng.device_alloc(16 * eng.big * 8)
+    try:
+        eng.device_upload(d_in, ct)
+        zero = np.zeros((16, eng.big), np.uint64)
+        for nv in (14, 13, 1):
+            want = eng.max_u16(ct[: nv * 16])
+            assert np.array_equal(eng.max_u16_io(d_in, nv, True), want)                      # device in, host out
+            eng.device_upload(d_out, zero)
+            eng.max_u16_io(d_in, nv, True, out_device_ptr=d_out)                             # device in, device out
+            assert np.array_equal(eng.device_download(d_out, (16, eng.big)), want)
+            eng.device_upload(d_out, zero)
+            eng.max_u16_io(ct[: nv * 16], nv, False, out_device_ptr=d_out)                   # host in, device out
+            assert np.array_equal(eng.device_download(d_out, (16, eng.big)), want)
+            assert np.array_equal(eng.device_download(d_in, ct.shape), ct)                   # the input is only read
+        mbits = r.O.lwe_decrypt_bits(r.keys.glwe_sk, eng.max_u16_io(d_in, 14, True))
+        assert int("".join(str(int(b)) for b in mbits), 2) == max(vals)
+        want = eng.inner_product_u16(ct[: 4 * 16])
+        assert np.array_equal(want, r.octx.inner_product_u16(ct[: 4 * 16]))
+        assert np.array_equal(eng.inner_product_u16_io(d_in, 4, True), want)
+        eng.device_upload(d_out, zero)
+        eng.inner_product_u16_io(d_in, 4, True, out_device_ptr=d_out)
+        assert np.array_equal(eng.device_download(d_out, (16, eng.big)), want)
+        assert np.array_equal(eng.device_download(d_in, ct.shape), ct)
+        # the transcipher's own device output feeds the max without leaving HBM: same ciphertexts as through the host
+        fx = [f for f in FIX if f["size"] == 0 and f["dataset_seed"] == 123][0]
+        ctb = bytes.fromhex(fx["db_hex"])
+        d_res = eng.device_alloc(128 * eng.big * 8)
+        try:
+            eng.transcipher(ctb, out_device_ptr=d_res)
+            host = eng.transcipher(ctb)
+            assert np.array_equal(eng.device_download(d_res, host.shape), host)
+            assert np.array_equal(eng.max_u16_io(d_res, 8, True), eng.max_u16(host))
+        finally:
+            eng.device_free(d_res)
+    finally:
+        eng.device_free(d_in); eng.device_free(d_out)
 
 
 def test_forced_process_group_of_one_runs_the_rccl_branch():
