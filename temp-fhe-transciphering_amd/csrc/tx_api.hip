@@ -38,6 +38,8 @@ struct tx_ctx {
     cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
     size_t auto_split_stride = 0;
     cplx *tw = nullptr, *tw256 = nullptr;
+    uint32_t *fair_tab = nullptr;           // k_blind_rotate6: step counters of the workgroups of every CU (tx_br2.hpp)
+    uint32_t br6_epoch = 0;                 // launch number of k_blind_rotate6: a table word of another launch is not a competitor
     int num_cus = 0;
     int trace_variant = 4;                  // k_extract_trace4 (generated trace loop); TX_TRACE_VARIANT=0: the hipcc kernel
     int ss_variant = 4;                     // k_scheme_switch4 (generated body); TX_SS_VARIANT=0: the hipcc kernel
@@ -118,6 +120,8 @@ static int upload_tables(tx_ctx *c)
     HIP_OK(hipMalloc(&c->tw256, t2.size() * sizeof(cplx)));
     HIP_OK(hipMemcpy(c->tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(c->tw256, t2.data(), t2.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->fair_tab, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t)));
+    HIP_OK(hipMemset(c->fair_tab, 0, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t)));
     return 0;
 }
 
@@ -143,16 +147,16 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     if (upload_tables(c) != 0) { tx_destroy(c); return nullptr; }
     // experiment knobs, parsed once and validated here (behind the stream and the tables, so that a bad value also
     // exercises the release of a half-built context)
-    if (env_knob("TX_BR_VARIANT", 0, 6, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
+    if (env_knob("TX_BR_VARIANT", 0, 7, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
         env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
         env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu) || env_knob("TX_CTR_SHARE", 0, 1, c->ctr_share)) { tx_destroy(c); return nullptr; }
     {
-        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6);
+        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6 || c->br_variant == 7);
 #ifdef TXD_WITH_BR3
         ok = ok || c->br_variant == 3;
 #endif
         if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4)) {
-            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5 or 6 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
+            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5, 6 or 7 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
             tx_destroy(c); return nullptr;
         }
     }
@@ -175,6 +179,8 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
                             (int)LDS_BYTES_BR5) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate6), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR6) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate7), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_BR7) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_BR3) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); tx_destroy(c); return nullptr;
@@ -208,7 +214,7 @@ extern "C" void tx_destroy(tx_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
-    hipFree(c->tw); hipFree(c->tw256); hipFree(c->luts); hipFree(c->ctr_luts);
+    hipFree(c->tw); hipFree(c->tw256); hipFree(c->fair_tab); hipFree(c->luts); hipFree(c->ctr_luts);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -299,6 +305,14 @@ extern "C" int tx_get_twiddles(tx_ctx *c, double *out)
 }
 
 #ifdef TXD_STAMPS
+// diagnostic builds only: the fairness table of k_blind_rotate6 (word 4 of an entry counts the workgroups that CU has hosted)
+extern "C" int tx_debug_fair_table(tx_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return fail("tx_debug_fair_table: null");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpy(out, c->fair_tab, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int tx_debug_wave_times(tx_ctx *c, unsigned long long *out, int n)
 {
     if (!c || !out || n > 2 * 4096) return fail("tx_debug_wave_times: bad argument");
@@ -465,7 +479,7 @@ static int br_plan(size_t count, int cus_, int forced, int variants[2], size_t c
 {
     if (count == 0) return 0;
     const size_t cus = (size_t)(cus_ > 0 ? cus_ : 1);
-    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 0; };
+    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 7; };
     if (forced >= 0) { variants[0] = forced; counts[0] = count; return 1; }
     if (count <= 4 * cus) { variants[0] = small(count); counts[0] = count; return 1; }
     const size_t pass = 8 * cus, rem = count % pass, full = count - rem;
@@ -488,11 +502,22 @@ static void br_used(tx_ctx *c, const char *kernel, size_t units)
 static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, uint64_t *acc)
 {
     const int n = (int)c->p.n;
-    br_used(c, variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" : variant == 4 ? "k_blind_rotate4" :
+    br_used(c, variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" : variant == 4 ? "k_blind_rotate4" :
                variant == 3 ? "k_blind_rotate3" : "k_blind_rotate", count);
-    if (variant == 6) {
+    if (variant == 7) {
+        ev_begin(c, F_BR, "k_blind_rotate7", count);
+        hipLaunchKernelGGL(k_blind_rotate7, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
+                           c->bsk_f, c->tw, c->fair_tab);
+    } else if (variant == 6) {
+        // launch number 0 = no arbitration: with at most one workgroup per CU there is nobody to be fair to
+        uint32_t ep = count <= (size_t)c->num_cus ? 0u : (++c->br6_epoch & 0x7FFFu);          // 15 bits above the 16-bit step count of a table word
+        if (ep == 0 && count > (size_t)c->num_cus) {                                   // wrapped: forget every word, so that none of 32 768 launches ago reads as current
+            hipMemsetAsync(c->fair_tab, 0, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t), c->stream);
+            ep = ++c->br6_epoch & 0x7FFFu;
+        }
         ev_begin(c, F_BR, "k_blind_rotate6", count);
-        hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+        hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw,
+                           c->fair_tab, ep << 16);
     } else if (variant == 5) {
         size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
         if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
@@ -520,17 +545,21 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     //         512-thread workgroup per CU, fair arbitration between the two waves of a SIMD); k_blind_rotate4 (the same loop
     //         in two independent 256-thread workgroups per CU) is 1 % behind it (TX_BR_VARIANT=4).
     //   <= 3  the launch time is the length of ONE CMux chain: k_blind_rotate6 puts three waves on every unit, one per
-    //         polynomial (tx_br2.hpp): 128 and 256 units 2.9 against 7.1 ms for the one-wave kernel, 512 units 4.5 against
-    //         7.4 ms, 768 units 6.1 against 7.5 ms.
-    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) twelve cooperative waves per CU queue at the LDS
-    //         pipeline and only tie with four one-wave units (7.7-8.1 against 7.5 ms), and a two-to-one split over two waves
-    //         per unit (tools/asmgen/brgen2.py) wins 3-9 % standalone and loses 3 % under sustained load: k_blind_rotate (one
-    //         wave per unit, hipcc; TX_BR_VARIANT=0: the plain form of the algorithm) runs here.
+    //         polynomial (tx_br2.hpp), and (round 4) keeps the workgroups of a CU level through a table of step counters and
+    //         s_setprio: 128 and 256 units 2.9 against 7.1 ms for the one-wave kernel, 512 units 4.0 (4.5 without the
+    //         fairness), 768 units 4.9 (5.8 without).  One workgroup per CU has nobody to be fair to (launch number 0).
+    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) k_blind_rotate7: the same loop with the four units
+    //         of a CU in ONE twelve-wave workgroup -- four independent three-wave workgroups need a packing of 168-register
+    //         waves the hardware's placement misses for a handful of workgroups per launch (9 ms instead of 6.5): 6.9 ms
+    //         against 7.5 ms for k_blind_rotate (one wave per unit, hipcc; TX_BR_VARIANT=0: the plain form of the algorithm).
     // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
     // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
     // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).
     size_t counts[2]; int variants[2];
     const int n_launch = br_plan(count, c->num_cus, c->br_variant, variants, counts);
+#ifdef TXD_SYNC_BEFORE_BR      // experiment: does the blind rotation start on a chip that is really empty?
+    hipStreamSynchronize(c->stream);
+#endif
     size_t done = 0;
     for (int i = 0; i < n_launch; i++) {
         launch_br(c, variants[i], in + done * (c->p.n + 1), counts[i], acc + done * GL);

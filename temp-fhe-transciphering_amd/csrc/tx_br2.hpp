@@ -436,21 +436,38 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // step.  The loop is generated (tools/asmgen/brgen3.py -> tx_br3_asm.inc, 168 registers: three waves per SIMD when the
 // launch fills the chip, four workgroups of 34 048 B LDS per CU); same products in the same order: bit-identical to
 // k_blind_rotate and the oracle.
+// Fair arbitration between the workgroups of a CU (round 4): the SIMD arbiter serves the oldest wave first, so the four
+// workgroups of a CU used to finish at 3.9, 5.0, 6.5 and 8.1 ms of a 1024-unit launch, the last one with ever fewer
+// neighbours to fill its stalls.  Every workgroup now publishes its step counter in its CU's entry of `fair_tab` (global
+// memory; the entry is found by the hardware's own CU number: XCC_ID and the CU / SH / SE fields of HW_ID; the word in the
+// entry by a counter the workgroups of the CU draw from), and the generated loop sets s_setprio by the lead over the slowest
+// workgroup of the same launch on the same CU (tools/asmgen/brgen3.py, fair_step).  Priorities only: no result depends on it.
 // ------------------------------------------------------------------------------------------
 constexpr int BR6_WAVES = 3;
-constexpr size_t LDS_BYTES_BR6 = BR3_TW_CPLX * sizeof(cplx) + BR6_WAVES * BR3_TILE_BYTES;
+constexpr int FAIR_TAB_ENTRIES = 4096, FAIR_TAB_WORDS = 8;      // [xcc 4 bits | se, sh, cu 8 bits] x (4 progress words, 1 slot counter, 3 unused)
+#include "tx_br3_asm_consts.inc"
+// + 1 KiB behind the tiles where the key prefetch drops what it touched, + the workgroup's word index in the fairness table
+constexpr size_t LDS_BYTES_BR6 = BR3_TW_CPLX * sizeof(cplx) + BR6_WAVES * BR3_TILE_BYTES + 1024 + 16;
 static_assert(4 * LDS_BYTES_BR6 <= 160 * 1024, "four workgroups per CU");
 
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g,
+                     uint32_t *fair_tab, uint32_t epoch_shl16)
 {
-    extern __shared__ __align__(16) unsigned char lds[];
+    extern __shared__ __align__(16) unsigned char lds[];         // (no static __shared__ here: the generated loop reads the twiddles at LDS address 0)
+    uint32_t &fair_slot = *reinterpret_cast<uint32_t *>(lds + LDS_BYTES_BR6 - 16);
     cplx *tw = reinterpret_cast<cplx *>(lds);
     for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
     if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int unit = (int)blockIdx.x;                   // the grid is `count` workgroups
     if (unit >= count) return;                          // (uniform per workgroup: no wave is left alone at a barrier)
+    // this CU's entry of the fairness table: s_getreg_b32 HW_REG_XCC_ID (register 20, 4 bits) and HW_REG_HW_ID (register 4:
+    // cu_id [11:8], sh_id [12], se_id [15:13]); simm16 = (size - 1) << 11 | offset << 6 | register
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    const uint32_t cu8 = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);
+    uint32_t *fair_entry = fair_tab + (size_t)(((xcc & 15u) << 8) | (cu8 & 255u)) * FAIR_TAB_WORDS;
+    if (threadIdx.x == 0) fair_slot = atomicAdd(fair_entry + 4, 1u) & 3u;      // consecutive draws: four distinct words
     unsigned char *tile0 = lds + BR3_TW_CPLX * sizeof(cplx);
     unsigned char *tile = tile0 + (size_t)wave * BR3_TILE_BYTES;
     uint64_t *pl = reinterpret_cast<uint64_t *>(tile);
@@ -475,6 +492,12 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     const uint32_t tile0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile0);
     const cplx *col = bsk_f + (size_t)wave * H;                         // key[q][c] of row i: col + (i * 9 + q * 3) * H
     uint64_t *out = acc_out + (size_t)unit * GL + (size_t)wave * N;
+    // key prefetch: every step this wave touches one 1 KiB piece (of 72) of the key row BR6_PF_ROWS steps ahead, so that the row is
+    // in L2 when it is needed; workgroups go to the XCDs round-robin, so (blockIdx.x >> 3) counts the workgroups of an XCD, and
+    // consecutive ones cover consecutive triples of pieces.  Relative to `col` (this wave's column of the current row).
+    const uint32_t piece = (3u * (blockIdx.x >> 3) + (uint32_t)wave) % (uint32_t)(KP * KP * 8);
+    const uint32_t pf_off = (uint32_t)BR6_PF_ROWS * (uint32_t)(KP * KP * H * sizeof(cplx)) + piece * 1024u - (uint32_t)wave * (uint32_t)(H * sizeof(cplx));
+    const uint32_t fair_off = __builtin_amdgcn_readfirstlane(fair_slot * 4u | pf_off << 4);      // (fair_slot: written before the __syncthreads above)
 #ifdef TXD_STAMPS_BR6   // diagnostic build: per-phase cycle sums of wave TXD_STAMP_THREAD / 64 of workgroup TXD_STAMP_BLOCK
     unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == (TXD_STAMP_THREAD / 64) % 3) ? txd_stamps : txd_stamps_sink;
     if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
@@ -483,7 +506,7 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm_stamps.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(dbg)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16), "s"(dbg)
         :
 #include "tx_br3_asm_clobbers.inc"
     );
@@ -492,7 +515,85 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16)
+        :
+#include "tx_br3_asm_clobbers.inc"
+    );
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blind_rotate7: the cooperative loop of k_blind_rotate6 with FOUR units in one workgroup of twelve waves (768 threads, one
+// workgroup per CU), for launches of exactly four units per CU -- the 8-blocks-per-GPU share of the medium instance: 1024 units.
+// Why a kernel of its own: four three-wave workgroups per CU need every SIMD to take exactly three waves of 168 registers
+// (504 of 512), and the hardware's placement of independent workgroups does not always find that packing: of 1024 workgroups
+// 4 to 36 start only when the first ones have finished (one CU then hosts 5 to 7 workgroups in turn while others sit at 3,
+// profiles/r4_coop_blind_rotation_placement.txt), which turns 6.4-6.7 ms into 9-10 ms.  The waves of ONE workgroup go to the
+// SIMDs in cyclic order, so twelve waves are three per SIMD by construction, and unit u = waves 3u, 3u + 1, 3u + 2 sits on
+// three different SIMDs.  s_barrier then spans all twelve waves: the four units advance in lockstep, which is also what
+// the fair arbitration of k_blind_rotate6 drives its workgroups to, without the table (launch number 0 switches it off).
+// Same generated loop, same results.  Units past `count` in the last workgroup shadow the last unit (every wave must reach
+// every barrier): they compute and store the same words.
+// ------------------------------------------------------------------------------------------
+constexpr int BR7_UNITS = 4;
+constexpr size_t LDS_BYTES_BR7 = BR3_TW_CPLX * sizeof(cplx) + BR7_UNITS * BR6_WAVES * BR3_TILE_BYTES + 1024;
+
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, uint32_t *fair_tab)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int u = wave / BR6_WAVES, c = wave % BR6_WAVES;
+    const int unit = min((int)blockIdx.x * BR7_UNITS + u, count - 1);
+    unsigned char *tile0 = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)(u * BR6_WAVES) * BR3_TILE_BYTES;      // the unit's three tiles
+    unsigned char *tile = tile0 + (size_t)c * BR3_TILE_BYTES;
+    uint64_t *pl = reinterpret_cast<uint64_t *>(tile);
+    const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+    if (c == KP - 1) {      // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+        const int rot = 2 * N - (int)modswitch(ct[n]);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int src = lane + 64 * m - rot;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            pl[lane + 64 * m] = (x ^ neg) - neg;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) pl[lane + 64 * m] = 0;
+    }
+    __syncthreads();
+    const uint32_t tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile);
+    const uint32_t tile0_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)tile0);
+    const cplx *col = bsk_f + (size_t)c * H;
+    uint64_t *out = acc_out + (size_t)unit * GL + (size_t)c * N;
+    const uint32_t piece = (3u * (blockIdx.x >> 3) * BR7_UNITS + (uint32_t)wave) % (uint32_t)(KP * KP * 8);
+    const uint32_t pf_off = (uint32_t)BR6_PF_ROWS * (uint32_t)(KP * KP * H * sizeof(cplx)) + piece * 1024u - (uint32_t)c * (uint32_t)(H * sizeof(cplx));
+    const uint32_t fair_off = __builtin_amdgcn_readfirstlane(pf_off << 4);
+    const uint32_t no_epoch = 0;        // nobody to be fair to: the barriers keep the four units together
+#ifdef TXD_STAMPS_BR6
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == (TXD_STAMP_THREAD / 64) % 3) ? txd_stamps : txd_stamps_sink;
+    if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = (unsigned long long)n;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const int rt_slot = (c == 0 && unit < 4096 && (int)blockIdx.x * BR7_UNITS + u < count) ? unit : -1;
+    asm volatile(
+#include "tx_br3_asm_stamps.inc"
+        :
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch), "s"(dbg)
+        :
+#include "tx_br3_asm_clobbers.inc"
+    );
+    if (rt_slot >= 0 && (threadIdx.x & 63) == 0) { txd_wave_rt[2 * rt_slot] = rt0; txd_wave_rt[2 * rt_slot + 1] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    asm volatile(
+#include "tx_br3_asm.inc"
+        :
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch)
         :
 #include "tx_br3_asm_clobbers.inc"
     );

@@ -24,7 +24,7 @@ import asmgen_emu_blind_rotate as one
 N, H, KP = one.N, one.H, one.KP
 TW_BYTES = one.TW_BYTES
 TILE_BYTES = 8320
-LDS_BYTES = TW_BYTES + 3 * TILE_BYTES
+LDS_BYTES = TW_BYTES + 3 * TILE_BYTES + 1024 + 16        # + the dump area of the key prefetch + the workgroup's fairness slot
 
 
 def run_group_ordered(emus, prog, order):
@@ -67,7 +67,8 @@ def main():
     for i in range(N):
         v = np.uint64(1) << np.uint64(63 - 2 * ((i & 7) + 1))
         tv[i] = (np.uint64(0) - v) if i < N // 2 else v
-    prog = brgen3.CoopGen(stamps=bool(os.environ.get("BR_STAMPS"))).build()
+    gen = brgen3.CoopGen(stamps=bool(os.environ.get("BR_STAMPS")))
+    prog, prog_fair = gen.build(), gen.cu_fair
     ok = True
     for order in ([0, 1, 2], [2, 1, 0]):
         lds = np.zeros(LDS_BYTES, np.uint8)
@@ -76,14 +77,22 @@ def main():
         for r in range(7): lw[8 * 64 + r * 8: 8 * 64 + r * 8 + 8] = tw[8 + r, :8]
         # what the kernel's HIP part leaves in the tiles: zero mask polynomials, the rotated test vector as the body
         lds[TW_BYTES + 2 * TILE_BYTES: TW_BYTES + 2 * TILE_BYTES + 8192].view(np.uint64)[:] = one.rotate(tv, rot0)
-        CT, ROW, OUT = 0x1000_0000, 0x2000_0000, 0x3000_0000
+        CT, ROW, OUT, TAB = 0x1000_0000, 0x2000_0000, 0x3000_0000, 0x5000_0000
+        # the CU's entry of the fairness table: this workgroup's word (slot 2), a competitor of this launch two steps ahead of
+        # the start, one that has finished, and a stale word of an older launch -- every priority path is taken over three steps
+        epoch = 0x0123 << 16
+        tab_buf = np.array([epoch | 2, epoch | 0xFFFF, 0xDEAD0007, (0x0122 << 16) | 1], np.uint32).view(np.uint8).copy()
         ct_buf = lwe.copy().view(np.uint8)
         key_buf = key.reshape(-1).view(np.uint8).copy()
         out_buf = np.zeros(KP * N * 8, np.uint8)
         SG = brgen.SG
         emus = []
         for c in range(3):
-            e = gcn.Emu(lds, [(CT, ct_buf), (ROW, key_buf), (OUT, out_buf)])
+            e = gcn.Emu(lds, [(CT, ct_buf), (ROW, key_buf), (OUT, out_buf), (TAB, tab_buf)])
+            e.s[brgen3.FTAB.i] = TAB; e.s[brgen3.FTAB.i + 1] = 0
+            # key prefetch: piece 5 + c of the row PF_ROWS steps ahead, relative to this wave's column pointer
+            pfoff = brgen3.PF_ROWS * KP * KP * H * 16 + (5 + c) * 1024 - c * H * 16
+            e.s[brgen3.FSLOT.i] = (8 | (pfoff << 4)) & 0xFFFFFFFF; e.s[brgen3.FEPOCH.i] = epoch
             for s, val in ((SG.CT, CT), (SG.ROW, ROW + c * H * 16), (SG.OUT, OUT + c * N * 8)):
                 e.s[s.i] = val & 0xFFFFFFFF; e.s[s.i + 1] = val >> 32
             e.s[SG.NSTEP.i] = steps
@@ -97,6 +106,9 @@ def main():
         run_group_ordered(emus, prog, order)
         got = out_buf.view(np.uint64).reshape(KP, N)
         same = np.array_equal(got, ref)
+        if prog_fair:            # the workgroup's word: "finished" at the end, the others untouched
+            tab = tab_buf.view(np.uint32)
+            same = same and tab[2] == (epoch | 0xFFFF) and tab[0] == (epoch | 2) and tab[3] == ((0x0122 << 16) | 1)
         ok = ok and same
         top = max(max((x.i + x.n) for x in i.a if isinstance(x, gcn.V)) for i in prog.ins if any(isinstance(x, gcn.V) for x in i.a))
         print("steps %d seed %d order %s: %d instructions per wave, top VGPR %d, %.1f s -> %s" %

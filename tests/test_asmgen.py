@@ -98,7 +98,7 @@ def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen3.py"), "--out", str(tmp_path)])
     # (the *_stamps.inc diagnostic variants the generators also write are build-time output, not tracked)
     for f in ("tx_fft_consts.inc", "tx_ss_asm.inc", "tx_br_asm.inc", "tx_br_asm_fair.inc", "tx_br_asm_clobbers.inc",
-              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc"):
+              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc", "tx_br3_asm_consts.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 
@@ -147,11 +147,12 @@ def test_scratch_of_the_built_kernels():
         hits = [v for n, v in k.items() if stem in n]
         assert len(hits) == 1, (stem, sorted(k))
         return hits[0]
-    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate4", "15k_blind_rotate6"):
+    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate4", "15k_blind_rotate6", "15k_blind_rotate7"):
         assert find(stem)["private_segment_fixed_size"] == 0, stem
     assert find("15k_blind_rotate5")["private_segment_fixed_size"] <= 128
     assert find("15k_blind_rotate5")["vgpr_count"] == 256 and find("15k_blind_rotate4")["vgpr_count"] == 256
     assert find("15k_blind_rotate6")["vgpr_count"] == 168            # three waves per SIMD
+    assert find("15k_blind_rotate7")["vgpr_count"] == 168            # twelve waves of one workgroup: three per SIMD
 
 
 def test_register_budget_and_no_scratch():

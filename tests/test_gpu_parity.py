@@ -466,7 +466,7 @@ def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
 def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     """BASELINE config 4's per-GPU share on one card: 31 blocks over FOUR ranks (gloo; a GPU box admits at most six
     processes on its card, so the node's eight ranks cannot be rehearsed here) = 8 + 8 + 8 + 7 blocks, i.e. launches
-    of 1024 and 896 units -- above three units per CU: the one-wave k_blind_rotate, as run_br dispatches -- a ragged gather, the gather of four partial
+    of 1024 and 896 units -- above three units per CU: k_blind_rotate7, as run_br dispatches -- a ragged gather, the gather of four partial
     maxima and the inner product's point-to-point step with 124 pairs dealt over four ranks"""
     import subprocess
     import sys as _sys
@@ -480,7 +480,7 @@ def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     line = _json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["checks"] == {"aes": True, "max": True, "inner_product": True}
-    assert line["blocks"] == 31 and line["ranks"] == 4 and line["blind_rotate_kernel"] == "k_blind_rotate"
+    assert line["blocks"] == 31 and line["ranks"] == 4 and line["blind_rotate_kernel"] == "k_blind_rotate7"
 
 
 @pytest.mark.gpu
@@ -520,12 +520,13 @@ def test_trace_and_scheme_switch_ring_stress(rig256):
     assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
 
 
-@pytest.mark.parametrize("variant", ["0", "4", "5", "6"])
+@pytest.mark.parametrize("variant", ["0", "4", "5", "6", "7"])
 @pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
 def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monkeypatch):
     """k_blind_rotate (hipcc, one wave per unit), k_blind_rotate4 / k_blind_rotate5 (generated assembly, two waves per SIMD,
-    csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair arbitration) and k_blind_rotate6 (generated, three waves per
-    unit, csrc/tx_br3_asm.inc), each forced on a small ragged launch: equals the oracle"""
+    csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair arbitration), k_blind_rotate6 (generated, three waves per
+    unit, csrc/tx_br3_asm.inc) and k_blind_rotate7 (the same loop, four units per twelve-wave workgroup: 13 units leave the
+    last workgroup with three shadow units), each forced on a small ragged launch: equals the oracle"""
     import txhip
     r = request.getfixturevalue(which)
     rng = np.random.default_rng(17)
@@ -538,7 +539,7 @@ def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monk
     e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)      # 13 units: a ragged last workgroup
     e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     got = e4.blind_rotate(lwe)
-    assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6"}[variant]
+    assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6", "7": "k_blind_rotate7"}[variant]
     one = e4.blind_rotate(lwe[5:6])                     # a single unit
     e4.close()
     assert np.array_equal(got, ref)
@@ -546,17 +547,28 @@ def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monk
 
 
 def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
-    """k_blind_rotate6 with the chip full of it -- 1024 units at n = 768 (four workgroups of three waves on every CU,
-    twelve waves per CU meeting at two barriers per step; forced: the dispatch gives launches above three units per CU
-    to the one-wave kernel) and 768 units as the dispatch itself picks it: same bits as the one-wave kernel on every
-    unit, twice (a race would not repeat), and the oracle's on a sample"""
+    """the cooperative loop with the chip full of it, n = 768: 1024 units as the dispatch picks them (k_blind_rotate7: one
+    twelve-wave workgroup of four units per CU), 1021 units (a ragged last workgroup: three shadow waves at every barrier),
+    1024 units forced through k_blind_rotate6 (four three-wave workgroups per CU competing under the fair arbitration -- table
+    of step counters, s_setprio -- some of them placed late) and 768 units as the dispatch picks them (k_blind_rotate6, three
+    workgroups per CU): same bits as the one-wave kernel on every unit, twice (a race would not repeat), and the oracle's on
+    a sample"""
     import txhip
     r = rig768
     rng = np.random.default_rng(37)
     cnt = 1024
     lwe = rng.integers(0, 1 << 63, (cnt, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.p.n + 1), dtype=np.uint64)
-    one_wave = r.eng.blind_rotate(lwe)
-    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate"
+    monkeypatch.setenv("TX_BR_VARIANT", "0")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    one_wave = e0.blind_rotate(lwe)
+    assert e0.last_blind_rotate_kernel() == "k_blind_rotate"
+    e0.close()
+    four = r.eng.blind_rotate(lwe)
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate7"
+    assert np.array_equal(four, one_wave) and np.array_equal(r.eng.blind_rotate(lwe), one_wave)
+    assert np.array_equal(r.eng.blind_rotate(lwe[:1021]), one_wave[:1021])
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate7"
     monkeypatch.setenv("TX_BR_VARIANT", "6")
     e6 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
     e6.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
@@ -565,10 +577,12 @@ def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
     assert np.array_equal(e6.blind_rotate(lwe), one_wave)
     e6.close()
     assert np.array_equal(coop, one_wave)
-    assert np.array_equal(r.eng.blind_rotate(lwe[:768]), one_wave[:768])
-    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate6"
+    for rep in range(2):
+        assert np.array_equal(r.eng.blind_rotate(lwe[:768]), one_wave[:768])
+        assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate6"
+    assert np.array_equal(r.eng.blind_rotate(lwe[:300]), one_wave[:300])        # two workgroups on some CUs, one on others
     pick = np.r_[0:3, cnt - 3:cnt]
-    assert np.array_equal(coop[pick], r.octx.blind_rotate(lwe[pick]))
+    assert np.array_equal(four[pick], r.octx.blind_rotate(lwe[pick]))
 
 
 def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):
@@ -767,5 +781,5 @@ def test_self_launch_refuses_more_ranks_than_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     t0 = _time.time()
     r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode != 0 and "needs 8 GPUs" in r.stderr and _time.time() - t0 < 120
+    assert r.returncode != 0 and "need 8 GPUs" in r.stderr and _time.time() - t0 < 120
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

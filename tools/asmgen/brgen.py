@@ -24,7 +24,7 @@ SGPR: see `SG` below.  LDS image: tx_br2.hpp (twiddles at 0, per wave: 8 320-byt
 import os
 import struct
 import sys
-from gcn import V, S, Lit, VCC, Prog
+from gcn import V, S, Lit, VCC, Prog, VCC_LO, VCC_HI, VCC64
 from fftconst import C16
 
 N, LOGN, H, KP = 1024, 10, 512, 3
@@ -98,6 +98,9 @@ class Gen:
         self.buf = None
         self.vmq = []          # in-flight vector-memory ops, oldest first: sets of destination registers
         self.lgq = []
+        self.valu_w = [set(), set()]   # VGPRs written by VALU instructions one / two wait states ago (cross-lane hazards)
+        self.xhi_regs = False  # True: exchange hi (register index <-> lane bits 5:3) in registers instead of through the tile
+        self.xlo_regs = False  # True: exchange lo (register index <-> lane bits 2:0) in registers as well
 
     # ---------------------------------------------------------------- emission + counters
     # Every emitted instruction goes through e(): registers it touches that are the destination of a load still in
@@ -115,6 +118,21 @@ class Gen:
                 if k is not None: self.p.emit("s_waitcnt", vm=k)
                 k = self._wait(self.lgq, touched, 15)
                 if k is not None: self.p.emit("s_waitcnt", lgkm=k)
+        # cross-lane instructions (v_permlane*_swap, DPP): 2 wait states after a VALU write of a VGPR they read; nothing inside an
+        # asm string is padded by the assembler, so the s_nop is emitted here
+        if "_swap_" in op or op.endswith("_dpp"):
+            rd = set()
+            for x in (a if "_swap_" in op else a[1:2]):
+                if isinstance(x, V): rd |= self.regs(x)
+            if rd & self.valu_w[0]: self.p.emit("s_nop", Lit(1)); self.valu_w = [set(), set()]
+            elif rd & self.valu_w[1]: self.p.emit("s_nop", Lit(0)); self.valu_w = [set(), self.valu_w[0]]
+        wrote = set()
+        if op.startswith("v_") and a and isinstance(a[0], V):
+            wrote = self.regs(a[0])
+            if "_swap_" in op: wrote |= self.regs(a[1])
+        if op not in ("label", "comment"):
+            nws = (a[0].v + 1) if op == "s_nop" else 1
+            for _ in range(min(nws, 2)): self.valu_w = [wrote, self.valu_w[0]]; wrote = set()
         self.p.emit(op, *a, **kw)
         if op.startswith("ds_read"): self.lgq.append(self.regs(a[0]))
         elif op.startswith("ds_write"): self.lgq.append(set())
@@ -404,6 +422,75 @@ class Gen:
     def xchg_hi_write(self, v):
         if "X" in ABL or "w" in ABL: return
         for r in range(8): self.ds_write("ds_write_b128", XHW, v[r], offset=128 * r)
+
+    def xchg_hi(self, v, spare):
+        """exchange hi of the eight quads v (element (lane 8a + b, register r) -> (lane 8r + b, register a)); returns the
+        eight quads that hold the result and the new spare quad"""
+        if self.xhi_regs and not ("X" in ABL): return self.xchg_hi_regs(v, spare)
+        self.xchg_hi_write(v)
+        free = sorted(v + [spare], key=lambda q: q.i)
+        v, spare = free[:8], free[8]
+        self.xchg_read(v, swz=False)
+        return v, spare
+
+    def swap_reg_bit_with_lane_bit(self, v, spare, step, from_lower, from_upper, mask_clear):
+        """pairs (r, r + step) of the eight quads v, r with that register-index bit clear: the lanes with the lane bit SET of the
+        lower register trade places with the lanes with it CLEAR of the upper one.  No swap instruction exists for lane bits 3..0,
+        so each register of a pair is rebuilt by one v_cndmask_b32 whose src0 is moved by DPP (`from_lower`: lane i reads lane
+        i - 2^bit, `from_upper`: lane i reads lane i + 2^bit) -- the first into the spare quad (its partner still needs the old
+        value), the second in place; the freed quad is the next pair's spare, and the pairs alternate which side goes first so
+        that vcc (mask_clear = the lanes with the bit clear, per 32) flips once per pair.  Returns (v, spare)."""
+        e = self.e
+        v = list(v)
+        e("s_mov_b32", VCC_LO, Lit(mask_clear)); e("s_mov_b32", VCC_HI, Lit(mask_clear))
+        low_first = True
+        tail = " row_mask:0xf bank_mask:0xf"
+        fl = from_lower + tail + (" bound_ctrl:0" if "sh" in from_lower else "")
+        fu = from_upper + tail + (" bound_ctrl:0" if "sh" in from_upper else "")
+        for r in [r for r in range(8) if not (r & step)]:
+            lo, hi = v[r], v[r + step]
+            if low_first:        # vcc = bit clear: new lo = own lanes where clear, the upper register's (moved up) where set
+                for k in range(4): e("v_cndmask_b32_dpp", V(spare.i + k), V(hi.i + k), V(lo.i + k), VCC, dpp=fl)
+                e("s_not_b64", VCC64, VCC64)
+                for k in range(4): e("v_cndmask_b32_dpp", V(hi.i + k), V(lo.i + k), V(hi.i + k), VCC, dpp=fu)
+                v[r], spare = spare, lo
+            else:                # vcc = bit set: new hi first
+                for k in range(4): e("v_cndmask_b32_dpp", V(spare.i + k), V(lo.i + k), V(hi.i + k), VCC, dpp=fu)
+                e("s_not_b64", VCC64, VCC64)
+                for k in range(4): e("v_cndmask_b32_dpp", V(lo.i + k), V(hi.i + k), V(lo.i + k), VCC, dpp=fl)
+                v[r + step], spare = spare, hi
+            low_first = not low_first
+        return v, spare
+
+    def xchg_hi_regs(self, v, spare):
+        """Exchange hi without LDS: the 3-bit register index is swapped with lane bits 5, 4, 3 one bit at a time.  Bit 5:
+        v_permlane32_swap (upper half of the first operand <-> lower half of the second); bit 4: v_permlane16_swap (odd rows of
+        the first <-> even rows of the second); bit 3: DPP row rotation by 8 (swap_reg_bit_with_lane_bit).  64 vector + 6 scalar
+        instructions for what 8 ds_write_b128 + 8 ds_read_b128 and a dependent LDS round trip did.  Same values in the same
+        registers of the same lanes: bit-identical by construction (tests/asmgen_emu_blind_rotate3.py runs both forms)."""
+        e = self.e
+        v = list(v)
+        for r in range(4):                                   # register bit 2 <-> lane bit 5
+            for k in range(4): e("v_permlane32_swap_b32", V(v[r].i + k), V(v[r + 4].i + k))
+        for r in (0, 1, 4, 5):                               # register bit 1 <-> lane bit 4
+            for k in range(4): e("v_permlane16_swap_b32", V(v[r].i + k), V(v[r + 2].i + k))
+        return self.swap_reg_bit_with_lane_bit(v, spare, 1, "row_ror:8", "row_ror:8", 0x00FF00FF)     # register bit 0 <-> lane bit 3
+
+    def xchg_lo(self, v, spare):
+        """exchange lo of the eight quads v (element (lane 8g + b, register r) -> (lane 8g + r, register b)); returns (v, spare)"""
+        if self.xlo_regs and not ("X" in ABL): return self.xchg_lo_regs(v, spare)
+        self.xchg_lo_write(v)
+        free = sorted(v + [spare], key=lambda q: q.i)
+        v, spare = free[:8], free[8]
+        self.xchg_read(v, swz=True)
+        return v, spare
+
+    def xchg_lo_regs(self, v, spare):
+        """Exchange lo without LDS: register-index bit j <-> lane bit j, j = 2, 1, 0: row shifts by 4, then the quad permutations
+        [2,3,0,1] and [1,0,3,2].  96 vector + 15 scalar instructions."""
+        v, spare = self.swap_reg_bit_with_lane_bit(v, spare, 4, "row_shr:4", "row_shl:4", 0x0F0F0F0F)
+        v, spare = self.swap_reg_bit_with_lane_bit(v, spare, 2, "quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", 0x33333333)
+        return self.swap_reg_bit_with_lane_bit(v, spare, 1, "quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", 0x55555555)
 
     def xchg_read(self, dst, swz):
         """row r of the tile, this lane's column (both exchanges read the same way; swz is kept for the call sites)"""

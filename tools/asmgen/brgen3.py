@@ -31,7 +31,7 @@ accumulator), X 112..159 (key ring of 12 quads; twiddles + spare in the transfor
 """
 import os
 import sys
-from gcn import V, S, Lit, VCC, Prog
+from gcn import V, S, Lit, VCC, Prog, M0
 import brgen
 from brgen import (Gen, SG, quad, qre, qim, f64bits, T0, T1, LANE, L8T, L16T, L16, OFF1, TWBA, XHW, XLW, EREG, L8, R10, R11,
                    CARRY, PITCH, N, H, KP, NSTAMP, ST_ACC, ST_DBG)
@@ -44,11 +44,36 @@ L16T0 = V(9)                             # tile of wave 0 + lane * 16
 TILE_STRIDE = 8 * PITCH                  # 8 320 bytes from one wave's tile to the next
 TILE0 = S(68)                            # LDS address of wave 0's tile
 ABL3 = os.environ.get("BR3_ABL", "")     # timing-only ablations (B no barriers, P no publish/read of transforms): outputs invalid
+# fair arbitration between the workgroups of a CU (below): their step counters live in one 32-byte entry of a table in global memory
+FTAB = S(66, 2)                          # this CU's table entry: four progress words
+FSLOT = S(69)                            # bits 3:0: byte offset of this workgroup's word in it; bits 31:4: PFOFF (key prefetch, below)
+PF_ROWS = int(os.environ.get("BR3_PF_ROWS", 0))       # the key row touched this many steps ahead of its use (0: no prefetch)
+PF_LDS = 3 * TILE_STRIDE                 # from wave 0's tile: 1 KiB behind the three tiles, where the touched bytes are dropped
+FEPOCH = S(59)                           # launch number << 16: a word of another launch is not a competitor
+FAIR_LEADS = [int(x) for x in os.environ.get("BR3_FAIR_LEADS", "2,4,8").replace("-", ",").split(",")]   # lead (steps) below which the priority is 3, 2, 1
 
 
 class CoopGen(Gen):
-    def __init__(self, stamps=False, prio=""):
+    def __init__(self, stamps=False, prio="", xhi_regs=None, xlo_regs=None, cu_fair=None):
         super().__init__(stamps=stamps, prio=prio, fair=False)
+        # Fair arbitration between the (up to four) workgroups of a CU.  The SIMD arbiter serves the oldest wave first, so the
+        # workgroups of a CU finish one after the other (1024 units: at 3.9, 5.0, 6.5 and 8.1 ms) and the last one runs with ever
+        # fewer neighbours to fill its stalls; the vector pipe, 78 % busy while all four are there (SQ_ACTIVE_INST_VALU x 3 waves
+        # / SQ_WAVE_CYCLES, profiles/r4d_*), idles in the tail.  Each workgroup therefore publishes its step counter in its CU's
+        # entry of a global table (one word per workgroup, tagged with the launch number), reads the entry one step ahead of its
+        # use, and sets its priority by its lead over the slowest workgroup of the entry: the slowest runs at s_setprio 3, a
+        # lead of FAIR_LEADS steps or more at 2, 1, 0.  All advance at the same rate and finish together.  Priorities only:
+        # results cannot depend on it.
+        self.cu_fair = (os.environ.get("BR3_FAIR", "1") == "1") if cu_fair is None else cu_fair
+        # BR3_XHI=regs: exchange hi of both transforms in registers (v_permlane32_swap / v_permlane16_swap / DPP) instead of
+        # through the tile: 32 of a step's 174 LDS instructions less per wave for 128 more vector instructions.  Measured
+        # (profiles/r4d_*): 2 % faster at one workgroup per CU, equal at three, slower at four -- there the vector pipe is
+        # the bound, not the LDS pipeline -- so the default stays the LDS form; both exchanges in registers lose everywhere
+        self.xhi_regs = (os.environ.get("BR3_XHI", "lds") == "regs") if xhi_regs is None else xhi_regs
+        # both exchanges in registers: the tile then only stages the rotation and carries the published transform, and the second
+        # barrier of a step (nobody still reads my tile) moves from the middle of the inverse to the next step's staging stores
+        self.xlo_regs = (os.environ.get("BR3_XLO", "lds") == "regs") if xlo_regs is None else xlo_regs
+        assert self.xhi_regs or not self.xlo_regs
 
     def barrier(self, phase):
         """every LDS operation of this wave has completed, then the workgroup's three waves meet (diagnostic build: the time
@@ -68,18 +93,12 @@ class CoopGen(Gen):
         self.c("forward: pass 1 (dft8, pass-A twiddles with the lane part of the twist, exchange hi)")
         v, spare = self.dft8(v, spare, +1)
         self.cmul_all([(v[r], tw[r]) for r in range(8)])
-        self.xchg_hi_write(v)
-        free = sorted(v + [spare], key=lambda q: q.i)
-        v, spare = free[:8], free[8]
-        self.xchg_read(v, swz=False)
+        v, spare = self.xchg_hi(v, spare)
         self.c("forward: pass 2 (dft8, pass-B twiddles, exchange lo)")
         self.load_tw(tw, 0, 7, compact=True)
         v, spare = self.dft8(v, spare, +1)
         self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)])
-        self.xchg_lo_write(v)
-        free = sorted(v + [spare], key=lambda q: q.i)
-        v, spare = free[:8], free[8]
-        self.xchg_read(v, swz=True)
+        v, spare = self.xchg_lo(v, spare)
         self.c("forward: pass 3 (dft8)")
         if before_pass3: before_pass3()            # the twiddle quads xq[0..7] are free from here on
         v, spare = self.dft8(v, spare, +1)
@@ -94,18 +113,12 @@ class CoopGen(Gen):
         self.load_tw(tw, 0, 7, compact=True)
         v, spare = self.dft8(v, spare, -1)
         hook()
-        self.xchg_lo_write(v)
-        free = sorted(v + [spare], key=lambda q: q.i)
-        v, spare = free[:8], free[8]
-        self.xchg_read(v, swz=True)
+        v, spare = self.xchg_lo(v, spare)
         self.c("inverse: pass 2' (pass-B twiddles conj, dft8, exchange hi)")
         self.cmul_all([(v[r], tw[r - 1]) for r in range(1, 8)], spare, conj=True)
         self.load_tw(tw, 0, 8)
         v, spare = self.dft8(v, spare, -1)
-        self.xchg_hi_write(v)
-        free = sorted(v + [spare], key=lambda q: q.i)
-        v, spare = free[:8], free[8]
-        self.xchg_read(v, swz=False)
+        v, spare = self.xchg_hi(v, spare)
         self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
         self.cmul_all([(v[r], tw[r]) for r in range(8)], spare, conj=True)
         home_lo = min(q.i for q in v)
@@ -150,11 +163,91 @@ class CoopGen(Gen):
         e("v_mov_b32", R10, Lit(0))
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0
         e("s_mov_b32", SG.I, Lit(0))
+        if self.cu_fair: self.fair_request()
         self.lg_wait_all()
         if self.stamps:
             for k in range(NSTAMP):
                 e("s_mov_b32", ST_ACC[k].lo(), Lit(0)); e("s_mov_b32", ST_ACC[k].hi(), Lit(0))
             self.stamp(None)
+
+    # ---------------------------------------------------------------- fair arbitration between the workgroups of a CU
+    FAIRQ = quad(E3, 0)                      # landing quad of the table entry: free outside the multiply-accumulate
+
+    def fair_request(self):
+        """the CU's table entry, a step ahead of its use (sc0 sc1: from L2, where the other workgroups' stores are).  (Also issued
+        under launch number 0, where nothing reads it: the loop head's full wait expects one outstanding load on either path.)"""
+        self.e("v_mov_b32", T0.lo(), Lit(0))
+        self.e("global_load_dwordx4", self.FAIRQ, T0.lo(), FTAB, offset=0, cache="sc0 sc1")
+
+    def fair_step(self):
+        """loop head (every vector-memory operation has retired): publish my step counter, take the entry requested a step
+        ago, priority by my lead over the slowest workgroup of this launch on this CU"""
+        e = self.e
+        self.c("---- fair arbitration: publish step, lead over the slowest workgroup of the CU -> s_setprio")
+        self.nlab += 1
+        off = "L_fo%d_%%=" % self.nlab
+        e("s_cmp_eq_u32", FEPOCH, Lit(0))                        # launch number 0: a launch that has nobody to be fair to
+        e("s_cbranch_scc1", off)
+        e("s_or_b32", SG.TMP, FEPOCH, SG.I)
+        e("s_and_b32", SG.TMP2, FSLOT, Lit(15))
+        e("v_mov_b32", T0.lo(), SG.TMP2)
+        e("v_mov_b32", T0.hi(), SG.TMP)
+        e("global_store_dword", T0.lo(), T0.hi(), FTAB, offset=0)
+        words = [SG.CTV.lo(), SG.CTV.hi(), SG.TMP, SG.TMP2]       # (all dead at the loop head)
+        for k in range(4): e("v_readfirstlane_b32", words[k], V(self.FAIRQ.i + k))
+        e("s_nop", Lit(3))
+        for k in range(4): e("s_xor_b32", words[k], words[k], FEPOCH)       # a word of this launch: its step count; of another: >= 2^16
+        e("s_min_u32", SG.TMP, SG.TMP, SG.TMP2)
+        e("s_min_u32", SG.CTV.lo(), SG.CTV.lo(), SG.CTV.hi())
+        e("s_min_u32", SG.TMP2, SG.TMP, SG.CTV.lo())
+        e("s_min_u32", SG.TMP2, SG.TMP2, SG.I)                   # (my own word may be a step old)
+        e("s_sub_u32", SG.TMP, SG.I, SG.TMP2)                    # my lead, >= 0
+        self.nlab += 1
+        done = "L_fp%d_%%=" % self.nlab
+        for prio, lead in zip((3, 2, 1), FAIR_LEADS):
+            nxt = "L_fq%d_%d_%%=" % (self.nlab, prio)
+            e("s_cmp_lt_u32", SG.TMP, Lit(lead))
+            e("s_cbranch_scc0", nxt)
+            e("s_setprio", Lit(prio))
+            e("s_branch", done)
+            self.p.label(nxt)
+        e("s_setprio", Lit(0))
+        self.p.label(done)
+        self.p.label(off)
+
+    def key_prefetch(self):
+        """EXPERIMENT, off by default (BR3_PF_ROWS=0): touch 1 KiB of the key row PF_ROWS steps ahead (LDS-DMA into a dump area: no
+        registers) so that it is in L2 when the multiply-accumulate asks for it.  Built on the suspicion that the round pipeline
+        (whose other kernels stream gigabytes between two blind rotations) costs the cooperative kernel its key in the caches;
+        measured, it does not: 8.5-9.1 ms with the prefetch against 8.2-8.9 ms without for 1024 units in the pipeline
+        (gpurun_out/r4g_sustained.log) -- what the pipeline costs there is workgroup PLACEMENT (k_blind_rotate7, tx_br2.hpp).
+        The row has 72 pieces of 1 KiB; the wrapper gives every wave one of them (PFOFF = PF_ROWS rows + piece - this wave's
+        column, relative to ROW).  Skipped for the last PF_ROWS steps (nothing behind the key)."""
+        e = self.e
+        if PF_ROWS == 0: return
+        self.nlab += 1
+        skip = "L_pf%d_%%=" % self.nlab
+        e("s_add_u32", SG.TMP, SG.I, Lit(PF_ROWS))
+        e("s_cmp_lt_u32", SG.TMP, SG.NSTEP)
+        e("s_cbranch_scc0", skip)
+        e("s_lshr_b32", SG.TMP, FSLOT, Lit(4))
+        e("s_add_u32", SG.CTV.lo(), SG.ROW.lo(), SG.TMP)
+        e("s_addc_u32", SG.CTV.hi(), SG.ROW.hi(), Lit(0))
+        e("s_add_u32", M0, TILE0, Lit(PF_LDS))
+        e("s_nop", Lit(0))
+        e("global_load_lds_dwordx4", L16, SG.CTV, offset=0)
+        self.vmq.append(set())
+        self.p.label(skip)
+
+    def fair_finish(self):
+        """this workgroup no longer competes (a word of 0xFFFF steps is never the minimum)"""
+        e = self.e
+        e("s_setprio", Lit(0))
+        e("s_or_b32", SG.TMP, FEPOCH, Lit(0xFFFF))
+        e("s_and_b32", SG.TMP2, FSLOT, Lit(15))
+        e("v_mov_b32", T0.lo(), SG.TMP2)
+        e("v_mov_b32", T0.hi(), SG.TMP)
+        e("global_store_dword", T0.lo(), T0.hi(), FTAB, offset=0)
 
     def step(self):
         e = self.e
@@ -162,6 +255,8 @@ class CoopGen(Gen):
         self.setprio("R")
         self.c("---- modswitch(ct[i]) -> rot; base = (lane - rot) mod 2N")
         self.p.emit("s_waitcnt", vm=0); self.vmq.clear()
+        if self.cu_fair: self.fair_step()
+        self.key_prefetch()
         e("v_readfirstlane_b32", SG.CTV.hi(), R11)
         e("s_nop", Lit(3))
         e("s_lshr_b32", SG.TMP, SG.CTV.hi(), Lit(23))           # x >> 55
@@ -211,6 +306,7 @@ class CoopGen(Gen):
         early(0, 3)
         # ---- rotation: stage the polynomial in the tile (natural order), gather the rotated words
         self.c("---- rotation: stage this wave's polynomial in its tile, gather rotated coefficients")
+        if self.xlo_regs: self.barrier(3)         # the neighbours have read the transform published in this tile a step ago
         for m in range(16): self.ds_write("ds_write_b64", L8T, V(A3 + 2 * m, 2), offset=512 * m)
         for m in range(8):
             self.ds_read("ds_read_b64", V(D3 + 4 * m, 2), RA3[m])
@@ -263,10 +359,11 @@ class CoopGen(Gen):
             for kk in (k, k + 1):
                 if kk + NG < len(stream): issue(kk + NG)
                 if kk + NL < len(stream): fetch(kk + NL)
+        if self.cu_fair: self.fair_request()                    # (the landing quads of the published transforms are free again)
         self.stamp(2)
         # ---- inverse; the tiles are free for its exchanges once every wave has read what it needs
         self.setprio("I")
-        v, sp2 = self.inv1_hooked(Fq, xq, lambda: self.barrier(3))
+        v, sp2 = self.inv1_hooked(Fq, xq, (lambda: None) if self.xlo_regs else (lambda: self.barrier(3)))
         self.stamp(3)
         self.setprio("U")
         self.c("---- this wave's polynomial += round(inverse)")
@@ -291,13 +388,16 @@ class CoopGen(Gen):
         e("s_add_u32", SG.I, SG.I, Lit(1))
         e("s_cmp_lt_u32", SG.I, SG.NSTEP)
         if "K" in brgen.ABL: self.vm_wait_all()
-        assert self.vmq == [] and self.lgq == [], (self.vmq, self.lgq)      # same state as at the loop head
+        # same state as at the loop head: nothing in flight but (fair mode) the table entry requested for the next step, which
+        # the full wait at the loop head -- or the epilogue's -- retires
+        assert self.lgq == [] and all(q == self.regs(self.FAIRQ) for q in self.vmq) and len(self.vmq) <= 1, (self.vmq, self.lgq)
         e("s_cbranch_scc1", "L_step%=")
 
     def epilogue(self):
         e = self.e
         self.c("---- epilogue: store this wave's polynomial (OUT points at it)")
         self.vm_wait_all()
+        if self.cu_fair: self.fair_finish()
         e("v_lshlrev_b32", L8, Lit(3), LANE)                    # (register 9: the published-transform address is dead)
         e("v_add_u32", T0.lo(), Lit(4096), L8)
         for m in range(16):
@@ -312,11 +412,14 @@ class CoopGen(Gen):
 
 
 def render_inc(prog, stamps=False):
-    """operands: %0 ct (64), %1 column c of bsk row 0 (64), %2 out + c N (64), %3 n, %4 this wave's tile, %5 wave 0's tile;
-    stamps: %6 the debug buffer (64)"""
+    """operands: %0 ct (64), %1 column c of bsk row 0 (64), %2 out + c N (64), %3 n, %4 this wave's tile, %5 wave 0's tile,
+    %6 this CU's entry of the fairness table (64), %7 byte offset of this workgroup's word in it | key prefetch offset << 4,
+    %8 launch number << 16;
+    stamps: %9 the debug buffer (64)"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
-            "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE, "s_mov_b32 %s, %%5" % TILE0]
-    if stamps: head.append("s_mov_b64 %s, %%6" % ST_DBG)
+            "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE, "s_mov_b32 %s, %%5" % TILE0,
+            "s_mov_b64 %s, %%6" % FTAB, "s_mov_b32 %s, %%7" % FSLOT, "s_mov_b32 %s, %%8" % FEPOCH]
+    if stamps: head.append("s_mov_b64 %s, %%9" % ST_DBG)
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen3.py -- do not edit"]
     for l in lines:
@@ -325,7 +428,7 @@ def render_inc(prog, stamps=False):
 
 
 def render_clobbers():
-    regs = ["v%d" % i for i in range(NV)] + ["s%d" % i for i in range(34, 96)] + ["vcc", "scc", "memory"]
+    regs = ["v%d" % i for i in range(NV)] + ["s%d" % i for i in range(34, 96)] + ["vcc", "scc"] + (["m0"] if PF_ROWS else []) + ["memory"]
     return "// generated by tools/asmgen/brgen3.py -- do not edit\n" + ", ".join('"%s"' % r for r in regs) + "\n"
 
 
@@ -335,6 +438,9 @@ if __name__ == "__main__":
         open(os.path.join(sys.argv[2], "tx_br3_asm.inc"), "w").write(render_inc(prog))
         open(os.path.join(sys.argv[2], "tx_br3_asm_stamps.inc"), "w").write(render_inc(CoopGen(stamps=True).build(), stamps=True))
         open(os.path.join(sys.argv[2], "tx_br3_asm_clobbers.inc"), "w").write(render_clobbers())
+        open(os.path.join(sys.argv[2], "tx_br3_asm_consts.inc"), "w").write(
+            "// generated by tools/asmgen/brgen3.py -- do not edit\n"
+            "constexpr int BR6_PF_ROWS = %d;      // the loop touches the key row this many steps ahead (and skips the last ones)\n" % PF_ROWS)
     elif len(sys.argv) > 1 and sys.argv[1] == "--count":
         c = prog.count()
         for k in sorted(c, key=lambda k: -c[k]): print("%6d %s" % (c[k], k))

@@ -52,6 +52,8 @@ class S:
 
     def __str__(self):
         if self.i == 124 and self.n == 1: return "m0"
+        if self.i == 106: return "vcc" if self.n == 2 else "vcc_lo"
+        if self.i == 107 and self.n == 1: return "vcc_hi"
         s = "s%d" % self.i if self.n == 1 else "s[%d:%d]" % (self.i, self.i + self.n - 1)
         return "-" + s if self.neg else s
 
@@ -68,6 +70,7 @@ class A:
 
 
 M0 = S(124)
+VCC_LO, VCC_HI, VCC64 = S(106), S(107), S(106, 2)      # gfx9 numbering of the vcc halves: what SALU instructions write
 
 
 class Lit:
@@ -102,6 +105,8 @@ class Ins:
         ops = ", ".join(str(x) for x in self.a)
         mods = ""
         if "offset" in self.kw and self.kw["offset"]: mods += " offset:%d" % self.kw["offset"]
+        if self.kw.get("dpp"): mods += " " + self.kw["dpp"]
+        if self.kw.get("cache"): mods += " " + self.kw["cache"]            # e.g. "sc0 sc1": a load that must see other workgroups' stores
         if self.kw.get("off"): ops = ops  # placeholder
         t = self.op + (" " + ops if ops else "") + mods
         return t
@@ -168,6 +173,7 @@ class Emu:
         self.H = _helpers()
         self.nexec = 0
         self.stats = {}
+        self.valu_recent = [set(), set()]            # VGPRs VALU instructions wrote one / two wait states ago
 
     # ---- register access
     def rd32(self, x):
@@ -253,7 +259,15 @@ class Emu:
         op, a, kw = i.op, i.a, i.kw
         f = getattr(self, "op_" + op, None)
         if f is None: raise NotImplementedError(op)
-        return f(*a, **kw)
+        r = f(*a, **kw)
+        # VGPRs written by VALU instructions, for the last two wait states (s_nop N counts N + 1)
+        wrote = set()
+        if op.startswith("v_") and a and isinstance(a[0], V):
+            wrote = set(range(a[0].i, a[0].i + a[0].n))
+            if "_swap_" in op: wrote |= set(range(a[1].i, a[1].i + a[1].n))
+        n = (int(a[0].v) + 1) if op == "s_nop" else 1
+        for _ in range(min(n, 2)): self.valu_recent = [wrote, self.valu_recent[0]]; wrote = set()
+        return r
 
     # ---- SALU
     def sval(self, x):
@@ -261,7 +275,20 @@ class Emu:
         if isinstance(x, Lit): return x.v & 0xFFFFFFFF
         raise TypeError(x)
 
-    def op_s_mov_b32(self, d, a): self.s[d.i] = self.sval(a)
+    def op_s_mov_b32(self, d, a):
+        self.s[d.i] = self.sval(a)
+        if d.i in (106, 107): self._vcc_from_s()
+
+    def _vcc_from_s(self):
+        bits = int(self.s[106]) | (int(self.s[107]) << 32)
+        self.vcc = np.array([(bits >> l) & 1 for l in range(64)], bool)
+
+    def op_s_not_b64(self, d, a):
+        assert d.i == 106 and a.i == 106 and d.n == 2, "only vcc is modelled as a 64-bit scalar mask"
+        self.vcc = ~self.vcc
+        bits = sum(1 << l for l in range(64) if self.vcc[l])
+        self.s[106], self.s[107] = bits & 0xFFFFFFFF, bits >> 32
+        self.scc = bits != 0
     def op_s_add_u32(self, d, a, b):
         r = self.sval(a) + self.sval(b); self.scc = r >> 32 != 0; self.s[d.i] = r & 0xFFFFFFFF
     def op_s_addc_u32(self, d, a, b):
@@ -281,11 +308,16 @@ class Emu:
     def op_s_lshr_b32(self, d, a, b): self.s[d.i] = self.sval(a) >> (self.sval(b) & 31)
     def op_s_lshl_b32(self, d, a, b): self.s[d.i] = (self.sval(a) << (self.sval(b) & 31)) & 0xFFFFFFFF
     def op_s_and_b32(self, d, a, b): self.s[d.i] = self.sval(a) & self.sval(b)
+    def op_s_or_b32(self, d, a, b): self.s[d.i] = self.sval(a) | self.sval(b)
+    def op_s_xor_b32(self, d, a, b): self.s[d.i] = self.sval(a) ^ self.sval(b)
+    def op_s_min_u32(self, d, a, b):
+        x, y = self.sval(a), self.sval(b); self.scc = x < y; self.s[d.i] = min(x, y)
     def op_s_cmp_lt_u32(self, a, b): self.scc = self.sval(a) < self.sval(b)
     def op_s_cbranch_scc1(self, lab): return lab if self.scc else None
     def op_s_cbranch_scc0(self, lab): return None if self.scc else lab
     def op_s_branch(self, lab): return lab
     def op_s_cmp_lg_u32(self, a, b): self.scc = self.sval(a) != self.sval(b)
+    def op_s_cmp_eq_u32(self, a, b): self.scc = self.sval(a) == self.sval(b)
     def op_s_cmp_gt_i32(self, a, b):
         x, y = self.sval(a), self.sval(b)
         x = x - (1 << 32) if x >> 31 else x; y = y - (1 << 32) if y >> 31 else y
@@ -380,6 +412,63 @@ class Emu:
 
     def op_v_readfirstlane_b32(self, d, a): self.s[d.i] = self.rd32(a)[0]
 
+    # ---- cross-lane (gfx950): half / row swaps between two registers, DPP row rotation
+    def _wait_states(self, *regs):
+        """2 wait states between a VALU write of a VGPR and a v_permlane*_swap / DPP instruction that reads it: the generator
+        pads with s_nop (nothing inside an asm string is padded by the assembler); the emulator refuses a stream that does not"""
+        for x in regs:
+            if x.i in self.valu_recent[0] or x.i in self.valu_recent[1]:
+                raise Poison("v%d read by a cross-lane instruction less than 2 wait states after a VALU wrote it" % x.i)
+
+    def op_v_permlane32_swap_b32(self, d, a):
+        """lanes 32..63 of the first operand <-> lanes 0..31 of the second"""
+        self._wait_states(d, a)
+        x, y = self.rd32(d), self.rd32(a)
+        nx, ny = x.copy(), y.copy()
+        nx[32:], ny[:32] = y[:32], x[32:]
+        self.wr32(d, nx); self.wr32(a, ny)
+
+    def op_v_permlane16_swap_b32(self, d, a):
+        """odd rows (16 lanes each) of the first operand <-> even rows of the second"""
+        self._wait_states(d, a)
+        x, y = self.rd32(d), self.rd32(a)
+        nx, ny = x.copy(), y.copy()
+        for row in (0, 2):
+            nx[16 * row + 16:16 * row + 32], ny[16 * row:16 * row + 16] = y[16 * row:16 * row + 16], x[16 * row + 16:16 * row + 32]
+        self.wr32(d, nx); self.wr32(a, ny)
+
+    @staticmethod
+    def _dpp_source_lanes(dpp):
+        """lane each lane reads src0 from under DPP control string `dpp` (-1: outside the row, reads 0 with bound_ctrl:0).
+        Modelled: quad_perm:[a,b,c,d], row_shl:n (lane i <- i + n), row_shr:n (lane i <- i - n), row_ror:n (lane i <- (i - n) mod 16
+        within its row of 16); full row / bank masks; the shifts only with bound_ctrl:0 (every lane executes)."""
+        import re
+        parts = dpp.split()
+        assert "row_mask:0xf" in parts and "bank_mask:0xf" in parts, dpp
+        ctrl = [x for x in parts if not x.startswith(("row_mask", "bank_mask", "bound_ctrl"))]
+        assert len(ctrl) == 1, dpp
+        c = ctrl[0]
+        src = np.zeros(64, np.int64)
+        m = re.match(r"quad_perm:\[(\d),(\d),(\d),(\d)\]$", c)
+        for l in range(64):
+            row, i = l & 48, l & 15
+            if m: src[l] = (l & ~3) | int(m.group(1 + (l & 3)))
+            elif c.startswith("row_ror:"): src[l] = row | ((i - int(c[8:])) & 15)
+            elif c.startswith("row_shr:"): src[l] = row | (i - int(c[8:])) if i - int(c[8:]) >= 0 else -1
+            elif c.startswith("row_shl:"): src[l] = row | (i + int(c[8:])) if i + int(c[8:]) <= 15 else -1
+            else: raise NotImplementedError(dpp)
+        if (src < 0).any(): assert "bound_ctrl:0" in parts, "a DPP shift without bound_ctrl:0 disables the lanes that read outside their row"
+        return src
+
+    def op_v_cndmask_b32_dpp(self, d, a, b, m, dpp=""):
+        """VOP2 with DPP on src0: d = vcc ? b : dpp(a)"""
+        assert m == "vcc", m
+        self._wait_states(a)
+        src = self._dpp_source_lanes(dpp)
+        x = self.rd32(a)
+        moved = np.where(src >= 0, x[np.maximum(src, 0)], 0).astype(np.uint32)
+        self.wr32(d, np.where(self.vcc, self.rd32(b), moved))
+
     # ---- VALU 64-bit float
     def op_v_mov_b64(self, d, a):
         self.wr32(V(d.i), self.rd32(V(a.i))); self.wr32(V(d.i + 1), self.rd32(V(a.i + 1)))
@@ -465,7 +554,7 @@ class Emu:
                 self.lds[m0 + 16 * l: m0 + 16 * l + 16] = arr[o:o + 16]
         self.vmq.append(([], apply))
 
-    def op_global_load_dwordx4(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 4)
+    def op_global_load_dwordx4(self, d, voff, sbase, offset=0, cache=None): self._gload(d, voff, sbase, offset, 4)
     def op_global_load_dwordx2(self, d, voff, sbase, offset=0): self._gload(d, voff, sbase, offset, 2)
 
     def _gstore(self, voff, src, sbase, offset, nd):
@@ -479,6 +568,7 @@ class Emu:
                 arr[o:o + 4 * nd].view(np.uint32)[:] = [v[l] for v in vals]
         self.vmq.append(([], apply))
 
+    def op_global_store_dword(self, voff, src, sbase, offset=0, cache=None): self._gstore(voff, src, sbase, offset, 1)
     def op_global_store_dwordx2(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 2)
     def op_global_store_dwordx4(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 4)
 
