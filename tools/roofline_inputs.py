@@ -73,16 +73,19 @@ def main():
     # vector-pipe occupancy of the kernel as it runs in the pipeline: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave, two waves per SIMD
     sq = one(os.path.join(ROOT, "gpurun_out", tag + "_pmc_blind_rotate5", "sq", "*counter_collection.csv"))
     lds = one(os.path.join(ROOT, "gpurun_out", tag + "_pmc_blind_rotate5", "lds", "*counter_collection.csv"))
-    acc = {}
-    for path in (sq, lds):
+    def sums(path):
+        a = {}
         for r in rows(path):
-            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        return a
+    a_sq, a_lds = sums(sq), sums(lds)            # two passes: each has its own SQ_WAVE_CYCLES
     src = keep(sq, tag + "_pmc_sq_blind_rotate5_in_pipeline.csv") + " + " + keep(lds, tag + "_pmc_lds_blind_rotate5_in_pipeline.csv")
-    per_wave = acc["SQ_ACTIVE_INST_VALU"] / acc["SQ_WAVE_CYCLES"]
+    per_wave = a_sq["SQ_ACTIVE_INST_VALU"] / a_sq["SQ_WAVE_CYCLES"]
+    frac = {k: v / a_sq["SQ_WAVE_CYCLES"] for k, v in sorted(a_sq.items()) if k.startswith(("SQ_ACTIVE", "SQ_WAIT"))}
+    frac.update({k: v / a_lds["SQ_WAVE_CYCLES"] for k, v in sorted(a_lds.items()) if k.startswith(("SQ_ACTIVE", "SQ_LDS"))})
     entries["vector_pipe_busy"] = {
         "kernel": KERNEL, "avg_units_per_launch": (8 * 8192 + 2048) / 9.0, "value": 2 * per_wave,
-        "per_wave": {k: acc[k] / acc["SQ_WAVE_CYCLES"] for k in sorted(acc) if k != "SQ_WAVE_CYCLES" and not k.startswith("SQ_INSTS") and k != "SQ_BUSY_CYCLES"},
-        "counters": acc,
+        "per_wave_fraction_of_wave_cycles": frac, "counters_sq_pass": a_sq, "counters_lds_pass": a_lds,
         "formula": "2 waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, summed over the k_blind_rotate5 launches of `bench.py --steps 1 --warmup 1`",
         "source": src, "stream_sha256": sha}
     doc = {"_about": "Counter-derived inputs of bench.py's roofline object. Each entry names the CSV(s) under profiles/ it was read from and "
