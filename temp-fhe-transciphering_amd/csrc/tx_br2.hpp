@@ -528,10 +528,11 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // Why a kernel of its own: four three-wave workgroups per CU need every SIMD to take exactly three waves of 168 registers
 // (504 of 512), and the hardware's placement of independent workgroups does not always find that packing: of 1024 workgroups
 // 4 to 36 start only when the first ones have finished (one CU then hosts 5 to 7 workgroups in turn while others sit at 3,
-// profiles/r4_coop_blind_rotation_placement.txt), which turns 6.4-6.7 ms into 9-10 ms.  The waves of ONE workgroup go to the
+// profiles/r4h_coop_blind_rotation_placement.txt), which turns 6.4-6.7 ms into 9-10 ms.  The waves of ONE workgroup go to the
 // SIMDs in cyclic order, so twelve waves are three per SIMD by construction, and unit u = waves 3u, 3u + 1, 3u + 2 sits on
 // three different SIMDs.  s_barrier then spans all twelve waves: the four units advance in lockstep, which is also what
-// the fair arbitration of k_blind_rotate6 drives its workgroups to, without the table (launch number 0 switches it off).
+// the fair arbitration of k_blind_rotate6 drives its workgroups to, without the table (launch number 0 switches it off);
+// running one half of the workgroup a barrier behind the other was measured slower (profiles/r4n_*).
 // Same generated loop, same results.  Units past `count` in the last workgroup shadow the last unit (every wave must reach
 // every barrier): they compute and store the same words.
 // ------------------------------------------------------------------------------------------
