@@ -184,6 +184,10 @@ class Gen:
         del q[:len(q) - keep]
         return keep
 
+    def even_lanes_to_vcc(self):
+        """vcc = the lanes with an even index: the carry-in mask of digit_pair's "+ e" (nothing else in the loops uses vcc)"""
+        self.e("s_mov_b32", VCC_LO, Lit(0x55555555)); self.e("s_mov_b32", VCC_HI, Lit(0x55555555))
+
     def vm_wait(self, regs): pass        # kept for call sites: e() places every wait
     def lg_wait(self, regs): pass
 
@@ -460,6 +464,7 @@ class Gen:
                 for k in range(4): e("v_cndmask_b32_dpp", V(lo.i + k), V(hi.i + k), V(lo.i + k), VCC, dpp=fl)
                 v[r + step], spare = spare, hi
             low_first = not low_first
+        self.even_lanes_to_vcc()                 # (digit_pair's carry mask)
         return v, spare
 
     def xchg_hi_regs(self, v, spare):
@@ -623,11 +628,13 @@ class Gen:
         self.e("v_subb_co_u32", hi, cy, hi, sgn, cy)
         self.e("v_sub_co_u32", lo, cy, lo, own_lo)
         self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
-        self.e("v_add_u32", t, Lit(0x100), hi)
-        self.e("v_bfe_u32", t, t, Lit(9), Lit(23))
-        self.e("v_sub_u32", t, t, EREG)
-        self.e("v_bfe_i32", t, t, Lit(0), Lit(23))
-        self.e("v_add_u32", t, t, EREG)
+        # digit = sext23(((hi + 0x100) >> 9) - e) + e with e = 1 on even coefficient indices (= even lanes), 0 on odd ones: the tie
+        # 2^22 goes to +B/2 there and to -B/2 here.  Three instructions (round 4; five before): EREG holds 0x100 - (e << 9), so one
+        # add rounds and shifts the tie, an arithmetic shift right by 9 of the 32-bit word IS the sign-extended 23-bit field, and
+        # "+ e" is the carry-in of a v_addc_co_u32 whose carry mask is vcc = the even lanes (set once in the prologue)
+        self.e("v_add_u32", t, hi, EREG)
+        self.e("v_ashrrev_i32", t, Lit(9), t)
+        self.e("v_addc_co_u32", t, cy, t, Lit(0), VCC)
         self.e("v_cvt_f64_i32", V(q.i, 2), t)
 
     def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB, cy=VCC):
@@ -670,7 +677,9 @@ class Gen:
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
         e("v_and_b32", T0.lo(), Lit(1), LANE)
-        e("v_sub_u32", EREG, Lit(1), T0.lo())
+        e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
+        e("v_add_u32", EREG, Lit(-0x100), EREG)
+        self.even_lanes_to_vcc()
         if self.fair:
             e("v_mov_b32", PARTNER, Lit(0))
             e("s_mov_b32", SG.FAIR, Lit(0))

@@ -145,7 +145,9 @@ class PairGen(brgen3.CoopGen):
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
         e("v_and_b32", T0.lo(), Lit(1), LANE)
-        e("v_sub_u32", EREG, Lit(1), T0.lo())
+        e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
+        e("v_add_u32", EREG, Lit(-0x100), EREG)
+        self.even_lanes_to_vcc()
         for name, val in (("C_2M64", 2.0 ** -64), ("C_M2P64", -(2.0 ** 64)), ("C_84", 1.5 * 2.0 ** 84), ("C_52", 1.5 * 2.0 ** 52),
                           ("C_SQH", 0.70710678118654752440)):
             s, b = getattr(SG, name), f64bits(val)
