@@ -592,7 +592,7 @@ static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t
                     uint64_t *out, const uint8_t *pos = nullptr)
 {
     ev_begin(c, F_LUT);
-    hipLaunchKernelGGL(k_lut_eval, dim3(grid_for(nbytes * nlut * 2)), dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
+    hipLaunchKernelGGL(k_lut_eval, dim3((grid_for(nbytes * nlut * 2) + 7) / 8 * 8), dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
                        lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
     ev_end(c);
 }

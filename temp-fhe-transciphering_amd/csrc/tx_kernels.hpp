@@ -929,6 +929,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds);
+    // XCD-aware unit order: the 2 nlut units of a byte read the same eight selector GGSWs (4 MB), and workgroups go to the eight
+    // XCDs round-robin, each XCD with an L2 of its own -- in launch order the units of a byte would sit on two XCDs and every
+    // GGSW would cross the fabric twice (7.4 GB per launch counted for 4.1 GB of GGSWs, profiles/r4m_pmc_fetch_size_bench_command.csv).
+    // Workgroup b therefore takes the units of logical workgroup (b mod 8) * (gridDim / 8) + b / 8: consecutive logical workgroups
+    // run on ONE XCD at adjacent dispatch times (the grid is a multiple of 8; surplus workgroups leave).
+    w.unit = (int)(((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * WAVES + (threadIdx.x >> 6));
     if (w.unit >= nbytes * nlut * 2) return;
     const int byte = w.unit / (nlut * 2), lut = (w.unit >> 1) % nlut, acc_idx = w.unit & 1;
     const int lane = w.lane;
