@@ -922,8 +922,11 @@ __device__ __forceinline__ void sample_extract_store(const uint64_t (&p0)[16], c
     if (w.lane == 0) o[2 * N] = w.pl[nth];
 }
 
+#ifndef LUT_WAVES_PER_EU
+#define LUT_WAVES_PER_EU 1, 1
+#endif
 // pos: AES byte position (0..15) of every byte, i.e. which keyed table it takes; null = byte index mod 16 (whole blocks)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUT_WAVES_PER_EU))) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
                                                   size_t byte_stride, uint64_t *out, int nbytes, int nlut,
                                                   const cplx *tw_g, const uint8_t *pos)
 {
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // cmux (SRV_CMP:81-95 via tfhe cmux_assign): ct0 += g (x) (ct1 - ct0), batched: unit u uses
 // selector sel[u] (index into ggsw_f), GLWEs ct0[u], ct1[u] (ct1 is not modified).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUT_WAVES_PER_EU))) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
                                               int units, const cplx *tw_g)
 {
     extern __shared__ __align__(16) unsigned char lds[];

@@ -81,6 +81,7 @@ def test_generated_scheme_switch_equals_oracle_four_waves(oracle):
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.experiments
 def test_trace_loop_variants_are_the_same_arithmetic(oracle):
     """the generator's alternatives kept for experiments: keys streamed by every wave instead of the shared ring, a
     deeper ring, transforms without the spread exchange stores"""
