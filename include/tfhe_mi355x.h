@@ -47,7 +47,7 @@ const char *tx_last_error(void);
 /* Replaces the key-conversion prologue of `main` (server_encrypted_aes_decryption.rs:640-687):
  * creates a context on HIP device `device`. */
 /* Experiment knobs (environment, read and validated ONCE here; an ill-formed or out-of-range value makes tx_create
- * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU, TX_CTR_SHARE.  Unset = the
+ * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_LUT_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU, TX_CTR_SHARE.  Unset = the
  * product path. */
 tx_ctx *tx_create(const tx_params *p, int device);
 void    tx_destroy(tx_ctx *c);

@@ -43,6 +43,8 @@ struct tx_ctx {
     int num_cus = 0;
     int trace_variant = 4;                  // k_extract_trace4 (generated trace loop); TX_TRACE_VARIANT=0: the hipcc kernel
     int ss_variant = 4;                     // k_scheme_switch4 (generated body); TX_SS_VARIANT=0: the hipcc kernel
+    int lut_variant = 0;                    // k_lut_eval (hipcc); TX_LUT_VARIANT=4: k_lut_eval4, the generated CMux tree (bit-identical, 10 % slower:
+                                            // 2.30 against 2.09 ms per launch of the medium instance, profiles/r4t_*)
     int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4|5 forces a kernel
     int br5_wgs = 0;                        // 0: one workgroup per CU; TX_BR5_WGS caps the persistent grid (experiments)
     int trss_wgs_per_cu = 1;                // TX_TRSS_WGS_PER_CU (experiments)
@@ -148,15 +150,16 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     // experiment knobs, parsed once and validated here (behind the stream and the tables, so that a bad value also
     // exercises the release of a half-built context)
     if (env_knob("TX_BR_VARIANT", 0, 7, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
-        env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
+        env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_LUT_VARIANT", 0, 4, c->lut_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
         env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu) || env_knob("TX_CTR_SHARE", 0, 1, c->ctr_share)) { tx_destroy(c); return nullptr; }
     {
         bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6 || c->br_variant == 7);
 #ifdef TXD_WITH_BR3
         ok = ok || c->br_variant == 3;
 #endif
-        if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4)) {
-            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5, 6 or 7 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT and TX_SS_VARIANT 0 or 4");
+        if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4) ||
+            (c->lut_variant != 0 && c->lut_variant != 4)) {
+            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5, 6 or 7 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT, TX_SS_VARIANT and TX_LUT_VARIANT 0 or 4");
             tx_destroy(c); return nullptr;
         }
     }
@@ -191,6 +194,8 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES_TR4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lut_eval4), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES_TR4) != hipSuccess) {
         fail("tx_create: cannot reserve LDS for the generated trace / scheme-switching kernels"); tx_destroy(c); return nullptr;
     }
@@ -592,8 +597,13 @@ static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t
                     uint64_t *out, const uint8_t *pos = nullptr)
 {
     ev_begin(c, F_LUT);
-    hipLaunchKernelGGL(k_lut_eval, dim3((grid_for(nbytes * nlut * 2) + 7) / 8 * 8), dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
-                       lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
+    const dim3 grid((grid_for(nbytes * nlut * 2) + 7) / 8 * 8);      // a multiple of 8: the kernels deal the units out XCD by XCD
+    if (c->lut_variant == 4)
+        hipLaunchKernelGGL(k_lut_eval4, grid, dim3(256), LDS_BYTES_TR4, c->stream, ggsw_f, lut_set,
+                           lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
+    else
+        hipLaunchKernelGGL(k_lut_eval, grid, dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
+                           lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
     ev_end(c);
 }
 // KS + CBS of `count` big LWEs into Fourier GGSWs

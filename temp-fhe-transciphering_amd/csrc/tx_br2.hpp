@@ -741,6 +741,81 @@ void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx 
     tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, lds_addr(slot0), lds_addr(tile));
 }
 
+// ------------------------------------------------------------------------------------------
+// a10 with the generated CMux tree (tools/asmgen/lutgen.py -> tx_lut_asm.inc): k_lut_eval with the explicit schedule of the
+// trace loop.  One wave per SIMD as before; the accumulator GLWE sits in the wave's LDS slice (the LDS image of the trace
+// kernels), the eight selector GGSWs of the byte stream from L2 through a twelve-quad register ring filled one and a half key
+// polynomials ahead, transforms three at a time with their exchange stores spread through the butterflies.  The wrapper
+// loads the keyed table, and extracts the four LWEs (coefficients 0, 256, 512, 768: bits 4 acc + i of the table entry) from
+// LDS afterwards.  Unit order as k_lut_eval: XCD-aware, the 2 nlut units of a byte on one XCD.  No barrier inside the
+// loop (every wave streams its own selector): a wave past the end leaves.  Bit-identical to k_lut_eval and the oracle.
+// NOT the default (TX_LUT_VARIANT=4 selects it): measured 2.30 ms against 2.09 ms for the hipcc kernel on the medium
+// instance.  In-kernel stamps, cycles per CMux step: difference + digits 18.0 k, 21 forward transforms 41.1 k, the 63 key
+// polynomials 55.7 k (880 cycles each: twelve quads in flight are one and a half polynomials, far less than the L2 round
+// trip), three inverses 5.9 k, update 3.7 k.  hipcc's schedule spends 480 registers on the same work and keeps more of the
+// selector in flight; parking the digit transforms in accumulation registers to widen the ring would bring the key pass to
+// ~20 k and the step to ~89 k against hipcc's ~95 k -- 0.3 % of a round -- and was not built (profiles/r4t_*).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_lut_eval4(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride, size_t byte_stride, uint64_t *out, int nbytes, int nlut,
+                 const cplx *tw_g, const uint8_t *pos)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    int wave; unsigned char *slot0;
+    unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
+    const int lane = threadIdx.x & 63;
+    const int unit = (int)(((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * WAVES) + wave;
+    if (unit >= nbytes * nlut * 2) return;
+    const int byte = unit / (nlut * 2), lut = (unit >> 1) % nlut, acc_idx = unit & 1;
+    const int table = pos ? (int)pos[byte] : (byte & 15);
+    const uint64_t *lp = luts + (size_t)lut * lut_stride + (size_t)table * byte_stride + (size_t)acc_idx * GL;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
+#pragma unroll
+    for (int q = 0; q < KP; q++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) gl[q * N + lane + 64 * m] = lp[q * N + lane + 64 * m];
+    const cplx *gg = ggsw_f + (size_t)byte * 8 * CBS_L * KP * KP * H;
+    const uint32_t tile_addr = lds_addr(tile);
+#ifdef TXD_STAMPS_LUT
+    unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
+    if (lane == 0 && dbg == txd_stamps) txd_stamps[6] = 8ull;
+    asm volatile(
+#include "tx_lut_asm_stamps.inc"
+        :
+        : "s"(gg), "s"(tile_addr), "s"(dbg)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#else
+    asm volatile(
+#include "tx_lut_asm.inc"
+        :
+        : "s"(gg), "s"(tile_addr)
+        :
+#include "tx_trace_asm_clobbers.inc"
+    );
+#endif
+    // the four LWEs of this accumulator: lwe[q N + j] = a_q[nth - j] (j <= nth), -a_q[N + nth - j] otherwise; body = b[nth]
+    const int lane2 = threadIdx.x & 63;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        const int nth = 256 * i;
+        uint64_t *o = out + (((size_t)lut * nbytes + byte) * 8 + acc_idx * 4 + i) * (size_t)BIG;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const int j = lane2 + 64 * m;
+                int src = nth - j;
+                uint64_t neg = 0;
+                if (src < 0) { src += N; neg = ~neg; }
+                const uint64_t x = gl[q * N + src];
+                o[q * N + j] = (x ^ neg) - neg;
+            }
+        if (lane2 == 0) o[2 * N] = gl[2 * N + nth];
+    }
+}
+
 // a6 + a7 + a8 + a9 in one kernel: the traced GLev element stays in the wave's LDS slice and goes straight into the
 // scheme switch -- no GLev round trip through HBM (24 KiB out and in per unit) and one workgroup start (twiddle image,
 // first loads) instead of two.  What run_cbs launches; the stage entry points keep the two kernels apart.

@@ -82,6 +82,13 @@ def test_generated_scheme_switch_equals_oracle_four_waves(oracle):
 
 
 @pytest.mark.experiments
+def test_generated_lut_tree_equals_oracle(oracle):
+    """tools/asmgen/lutgen.py (k_lut_eval4, selectable with TX_LUT_VARIANT=4): eight CMux steps in the emulator against a reference
+    built from the oracle's primitives on the whole accumulator, and against txo_lut_eval's four extracted LWEs"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_lut.py"), "8", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
+
+
 def test_trace_loop_variants_are_the_same_arithmetic(oracle):
     """the generator's alternatives kept for experiments: keys streamed by every wave instead of the shared ring, a
     deeper ring, transforms without the spread exchange stores"""
@@ -97,9 +104,10 @@ def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "fftconst.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "ssgen.py"), "--out", str(tmp_path)])
     subprocess.check_call([sys.executable, os.path.join(GEN, "brgen3.py"), "--out", str(tmp_path)])
+    subprocess.check_call([sys.executable, os.path.join(GEN, "lutgen.py"), "--out", str(tmp_path)])
     # (the *_stamps.inc diagnostic variants the generators also write are build-time output, not tracked)
     for f in ("tx_fft_consts.inc", "tx_ss_asm.inc", "tx_br_asm.inc", "tx_br_asm_fair.inc", "tx_br_asm_clobbers.inc",
-              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc", "tx_br3_asm_consts.inc"):
+              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc", "tx_br3_asm_consts.inc", "tx_lut_asm.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 

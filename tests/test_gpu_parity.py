@@ -109,6 +109,30 @@ def test_lut_eval_bit_identical_and_correct(rig256):
         assert np.array_equal(out_g, out_o)
 
 
+def test_lut_tree_kernels_agree(rig256, monkeypatch):
+    """k_lut_eval4 (generated CMux tree, TX_LUT_VARIANT=4; tools/asmgen/lutgen.py) and k_lut_eval (hipcc, the default) on a launch
+    of 37 bytes (a ragged last workgroup; more workgroups than XCDs, so the XCD-aware unit order matters) for every table
+    count the schedules use: the same LWEs bit for bit, and the oracle's on the first bytes; random Fourier GGSWs (the tree is
+    deterministic arithmetic on whatever selectors it gets)"""
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(61)
+    nbytes = 37
+    gf = rng.standard_normal(nbytes * 8 * r.p.cbs_level * 3 * 3 * 1024) * 2.0 ** 40
+    monkeypatch.setenv("TX_LUT_VARIANT", "4")
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    e0.load_round_luts(r.luts); e0.load_ctr_luts(r.ctr_luts)
+    gl = r.octx.gl
+    for (ctr, st, nlut, blob, mults) in [(1, 2, 3, r.ctr_luts, 3), (1, 9, 1, r.ctr_luts, 3), (0, 5, 4, r.luts, 4)]:
+        old = r.eng.lut_eval(gf, ctr, st, nlut)
+        new = e0.lut_eval(gf, ctr, st, nlut)
+        assert np.array_equal(new, old), (ctr, st, nlut)
+        want = r.octx.lut_eval(gf[: 2 * 8 * r.p.cbs_level * 9 * 1024], blob[st * mults * 16 * 2 * gl:], nlut, 2 * gl, 16 * 2 * gl)
+        assert np.array_equal(new.reshape(nlut, nbytes, 8, -1)[:, :2].reshape(nlut, 16, -1), want), (ctr, st, nlut)
+    e0.close()
+
+
 def test_partial_schedule_bit_identical_n256(rig256):
     """rounds 10/9 + two bootstrapped rounds of two blocks, ciphertext-level equality"""
     r = rig256
