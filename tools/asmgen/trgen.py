@@ -55,6 +55,9 @@ class TraceGen(Gen):
     def __init__(self, steps=LOGN, stop_after=None, stamps=False):
         super().__init__(stamps=stamps, prio="")
         self.steps = steps                # debugging: fewer trace steps
+        # TR_XHI=regs: exchange hi of every transform in registers (Gen.xchg_hi_regs) instead of through the tile -- a lone wave
+        # pays 53 cycles per ds_write_b128 when the four waves of the workgroup store together
+        self.xhi_regs = os.environ.get("TR_XHI", "lds") == "regs"
         self.stop_after = stop_after      # debugging: leave the step after phase "G" (digits parked), "B" (body), "M0" ...
 
     # ------------------------------------------------------------------ transforms of a wave that is alone on its SIMD
@@ -102,13 +105,14 @@ class TraceGen(Gen):
                 if pas == 1: self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spares[p], conj=True)
                 polys[p], spares[p] = self.dft8(polys[p], spares[p], -1)
                 if pas == 1: polys[p], spares[p] = self.home(polys[p], spares[p], home_lo[p], home_lo[p] + 32)
+                if pas == 2 and self.xhi_regs: polys[p], spares[p] = self.xchg_hi_regs(polys[p], spares[p])
             return f
         items = []
         for pas in (3, 2, 1):
             for p in range(3):
                 st = None
                 if pas == 3: st = (lambda p=p: self.xchg_lo_write(polys[p]))
-                if pas == 2: st = (lambda p=p: self.xchg_hi_write(polys[p]))
+                if pas == 2 and not self.xhi_regs: st = (lambda p=p: self.xchg_hi_write(polys[p]))
                 items.append((valu(pas, p), st, reread(p) if st else None))
         self._pipeline(items)
         self.substamp("inv3", 2)
@@ -140,6 +144,7 @@ class TraceGen(Gen):
                 if pas == 1:
                     self.cmul_all([(polys[p][r], tw[r]) for r in range(8)])
                     if p == 2: self.load_tw(tw, 0, 7, compact=True)
+                    if self.xhi_regs: polys[p], spares[p] = self.xchg_hi_regs(polys[p], spares[p])
                 if pas == 2: self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)])
                 if pas == 3: polys[p], spares[p] = self.home(polys[p], spares[p], home_lo[p], home_lo[p] + 32)
             return f
@@ -147,7 +152,7 @@ class TraceGen(Gen):
         for pas in (1, 2, 3):
             for p in range(3):
                 st = None
-                if pas == 1: st = (lambda p=p: self.xchg_hi_write(polys[p]))
+                if pas == 1 and not self.xhi_regs: st = (lambda p=p: self.xchg_hi_write(polys[p]))
                 if pas == 2: st = (lambda p=p: self.xchg_lo_write(polys[p]))
                 items.append((valu(pas, p), st, reread(p) if st else None))
         self._pipeline(items)
