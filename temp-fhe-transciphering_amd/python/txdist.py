@@ -50,6 +50,13 @@ def launch_ranks(script, argv, n, backend="nccl", need_gpu=True, prepare=None, n
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
     rc = 0
+
+    def forward(signum, frame):                  # the launcher being stopped stops its ranks (exactly those PIDs)
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    import signal
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
     try:
         live = list(procs)
         while live and rc == 0:
@@ -59,7 +66,7 @@ def launch_ranks(script, argv, n, backend="nccl", need_gpu=True, prepare=None, n
                 if r is not None:
                     live.remove(p)
                     if r != 0:
-                        rc = r
+                        rc = r if r > 0 else 128 - r          # a rank killed by signal n: 128 + n, as a shell reports it
                         print(f"{name}: rank {procs.index(p)} exited with status {r}; stopping the other ranks", file=sys.stderr)
                         break
     finally:
@@ -72,6 +79,8 @@ def launch_ranks(script, argv, n, backend="nccl", need_gpu=True, prepare=None, n
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
