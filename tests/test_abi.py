@@ -245,3 +245,21 @@ def test_blind_rotation_launch_plan():
         plan = P(count)
         assert sum(n for _, n in plan) == count and all(n > 0 for _, n in plan) and len(plan) <= 2
     assert P(300, num_cus=64) == [(5, 300)] and P(190, num_cus=64) == [(6, 190)]
+
+
+def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
+    """the entry points added in round 4 fail with a message (never crash, never touch a device) on null contexts / pointers"""
+    import txhip
+    L = txhip.lib()
+    assert L.tx_timing_size() == C.sizeof(txhip.TxTiming) == 112
+    assert not L.tx_device_alloc(None, 1024) and b"null context" in L.tx_last_error()
+    assert L.tx_device_free(None, None) < 0 and L.tx_device_upload(None, None, None, 8) < 0 and L.tx_device_download(None, None, None, 8) < 0
+    assert L.tx_max_u16_io(None, None, 4, None, 1, 1) < 0 and b"tx_max_u16" in L.tx_last_error()
+    assert L.tx_inner_product_u16_io(None, None, 4, None, 1, 1) < 0
+    L.tx_stage_circuit_bootstrap.restype = C.c_int
+    assert L.tx_stage_circuit_bootstrap(None, None, 1, None) < 0
+    # the CTR column grouping refuses a block count whose indices do not fit its int arrays (before it touches them)
+    iv = (C.c_uint8 * 16)()
+    assert L.tx_ctr_shared_columns(iv, 0, (1 << 29) + 1, None, None) < 0
+    one = (C.c_int * 4)(); two = (C.c_int * 4)()
+    assert L.tx_ctr_shared_columns(iv, 0, (1 << 29) + 1, one, two) < 0 and b"does not fit" in L.tx_last_error()
