@@ -101,6 +101,13 @@ class Gen:
         self.valu_w = [set(), set()]   # VGPRs written by VALU instructions one / two wait states ago (cross-lane hazards)
         self.xhi_regs = False  # True: exchange hi (register index <-> lane bits 5:3) in registers instead of through the tile
         self.xlo_regs = False  # True: exchange lo (register index <-> lane bits 2:0) in registers as well
+        # The accumulator is kept NEGATED inside the loop (round 4).  A CMux step needs d = +-acc[j + rot] - acc[j] and
+        # acc[j] += round(x): with acc' = -acc these are d = -+acc'[j + rot] + acc'[j] and acc'[j] += round(-x) -- both plain 64-bit
+        # ADDS (one v_lshl_add_u64 each: 4 cycles, where the v_sub_co_u32 / v_subb_co_u32 and v_add_co_u32 / v_addc_co_u32 pairs
+        # cost 8), the first with the gather's sign mask inverted (free: the literal of its index add) and the second with the
+        # negation on the source modifiers of the rounding's first two operations.  The polynomials are negated once on the way in
+        # and once on the way out (per unit, outside the loop).  Same integers mod 2^64 at every step: bit-identical.
+        self.neg_acc = True
 
     # ---------------------------------------------------------------- emission + counters
     # Every emitted instruction goes through e(): registers it touches that are the destination of a load still in
@@ -183,6 +190,11 @@ class Gen:
         keep = min(len(q) - (idx + 1), limit)
         del q[:len(q) - keep]
         return keep
+
+    def negate64(self, pair, cy):
+        """pair <- -pair (two's complement), carry mask cy"""
+        self.e("v_sub_co_u32", pair.lo(), cy, Lit(0), pair.lo())
+        self.e("v_subb_co_u32", pair.hi(), cy, Lit(0), pair.hi(), cy)
 
     def even_lanes_to_vcc(self):
         """vcc = the lanes with an even index: the carry-in mask of digit_pair's "+ e" (nothing else in the loops uses vcc)"""
@@ -626,8 +638,12 @@ class Gen:
         self.e("v_xor_b32", hi, hi, sgn)
         self.e("v_sub_co_u32", lo, cy, lo, sgn)
         self.e("v_subb_co_u32", hi, cy, hi, sgn, cy)
-        self.e("v_sub_co_u32", lo, cy, lo, own_lo)
-        self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
+        if self.neg_acc:         # the words are those of -acc and sgn is the inverted mask: -+acc'[j + rot] + acc'[j]
+            assert own_hi.i == own_lo.i + 1 and own_lo.i % 2 == 0
+            self.e("v_lshl_add_u64", V(q.i, 2), V(q.i, 2), Lit(0), V(own_lo.i, 2))
+        else:
+            self.e("v_sub_co_u32", lo, cy, lo, own_lo)
+            self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
         # digit = sext23(((hi + 0x100) >> 9) - e) + e with e = 1 on even coefficient indices (= even lanes), 0 on odd ones: the tie
         # 2^22 goes to +B/2 there and to -B/2 here.  Three instructions (round 4; five before): EREG holds 0x100 - (e << 9), so one
         # add rounds and shifts the tie, an arithmetic shift right by 9 of the 32-bit word IS the sign-extended 23-bit field, and
@@ -637,19 +653,29 @@ class Gen:
         self.e("v_addc_co_u32", t, cy, t, Lit(0), VCC)
         self.e("v_cvt_f64_i32", V(q.i, 2), t)
 
-    def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB, cy=VCC):
-        """dst = cur + round-half-even(x) mod 2^64 (torus_add_f64 of tx_device.hpp); x: f64 pair (destroyed);
-        tA, tB: temporary pairs"""
-        self.e("v_mul_f64", tA, x, SG.C_2M64)
+    def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB, cy=VCC, neg=False):
+        """dst = cur + round-half-even(x) mod 2^64 (torus_add_f64 of tx_device.hpp); x: f64 pair (destroyed); tA, tB: temporary
+        pairs.  neg: dst = cur - round(x) instead -- rounding to nearest even is symmetric, so that is cur + round(-x), and the
+        negation rides on the source modifiers of the first two operations.  The rounded value is assembled in x itself (low
+        dword: the 2^52 magic's mantissa; high dword: bits(t1).lo + bits(t2).hi - 0x43380000) and added by ONE v_lshl_add_u64
+        where the operands are aligned pairs (round 4: v_add_co_u32 + v_addc_co_u32 cost 4 cycles each, the 64-bit add 4 in all,
+        tools/microbench/insn_rate.hip)."""
+        xs = -x if neg else x
+        self.e("v_mul_f64", tA, xs, SG.C_2M64)
         self.e("v_rndne_f64", tA, tA)
-        self.e("v_fma_f64", x, tA, SG.C_M2P64, x)              # ys
+        self.e("v_fma_f64", x, tA, SG.C_M2P64, xs)             # ys
         self.e("v_add_f64", tA, x, SG.C_84)                    # t1
         self.e("v_add_f64", tB, tA, -SG.C_84)                  # h
         self.e("v_add_f64", x, x, -tB)                         # lo
         self.e("v_add_f64", x, x, SG.C_52)                     # t2
-        self.e("v_add3_u32", tA.lo(), tA.lo(), x.hi(), SG.C_M4338)     # rhi = bits(t1).lo + bits(t2).hi - 0x43380000
-        self.e("v_add_co_u32", dst_lo, cy, cur_lo, x.lo())
-        self.e("v_addc_co_u32", dst_hi, cy, cur_hi, tA.lo(), cy)
+        pair = lambda lo, hi: isinstance(lo, V) and isinstance(hi, V) and hi.i == lo.i + 1 and lo.i % 2 == 0
+        if pair(cur_lo, cur_hi) and pair(dst_lo, dst_hi):
+            self.e("v_add3_u32", x.hi(), tA.lo(), x.hi(), SG.C_M4338)      # rhi = bits(t1).lo + bits(t2).hi - 0x43380000, next to the low dword
+            self.e("v_lshl_add_u64", V(dst_lo.i, 2), x, Lit(0), V(cur_lo.i, 2))
+        else:
+            self.e("v_add3_u32", tA.lo(), tA.lo(), x.hi(), SG.C_M4338)
+            self.e("v_add_co_u32", dst_lo, cy, cur_lo, x.lo())
+            self.e("v_addc_co_u32", dst_hi, cy, cur_hi, tA.lo(), cy)
 
     # ---------------------------------------------------------------- the kernel
     def prologue(self):
@@ -691,6 +717,13 @@ class Gen:
         e("s_mov_b32", SG.C_M4338, Lit((-0x43380000) & 0xFFFFFFFF))
         for q in range(2):
             for m in range(32): e("v_mov_b32", V(A[q] + m), Lit(0))
+        if self.neg_acc:         # the loop works on -acc: the mask polynomials are 0 either way, the body is negated in place
+            W = [V(X + 2 * j, 2) for j in range(16)]
+            for j in range(16): self.ds_read("ds_read_b64", W[j], L8T, offset=BODY + 512 * j)
+            for j in range(16):
+                self.negate64(W[j], CARRY[j % 4])
+                self.ds_write("ds_write_b64", L8T, W[j], offset=BODY + 512 * j)
+            self.lg_wait_all()
         e("v_mov_b32", R10, Lit(0))
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0 (voffset register = its own dst: read at issue)
         e("s_mov_b32", SG.I, Lit(0))
@@ -725,7 +758,7 @@ class Gen:
         e("v_lshl_add_u32", R11, R11, Lit(3), SG.TILE)          # tile + (base & 63) * 8
         for m in range(16):
             t = T0.hi()
-            e("v_add_u32", t, Lit(m), R10)
+            e("v_add_u32", t, Lit(m + (16 if self.neg_acc else 0)), R10)      # (+ 16: the mask inverted, for the negated accumulator)
             e("v_bfe_i32", SGN[m], t, Lit(4), Lit(1))           # 0 / -1: coefficient comes from the negated half
             e("v_and_b32", t, Lit(15), t)
             e("v_lshl_add_u32", RA[m], t, Lit(9), R11)
@@ -847,9 +880,9 @@ class Gen:
                 x = V(v[m].i + 2 * half, 2)
                 if col < 2:
                     al, ah = V(A[col] + 2 * j), V(A[col] + 2 * j + 1)
-                    self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k])
+                    self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k], neg=self.neg_acc)
                 else:
-                    self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tmp[k][0], tmp[k][1], CARRY[k])
+                    self.torus_add(x, CUR[j].lo(), CUR[j].hi(), CUR[j].lo(), CUR[j].hi(), tmp[k][0], tmp[k][1], CARRY[k], neg=self.neg_acc)
                     self.ds_write("ds_write_b64", L8T, CUR[j], offset=BODY + 512 * j)
             chains = []
             for m in range(8):
@@ -890,6 +923,7 @@ class Gen:
                     src = V(X + 2 * m, 2)
                     self.ds_read("ds_read_b64", src, L8T, offset=BODY + 512 * m)
                     self.lg_wait(self.regs(src))
+                if self.neg_acc: self.negate64(src, CARRY[m % 4])           # back to acc
                 self.gstore("global_store_dwordx2", L8 if m < 8 else T0.lo(), src, SG.KP0, offset=512 * (m & 7))
         self.vm_wait_all()
         if self.stamps:

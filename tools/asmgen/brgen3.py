@@ -162,6 +162,8 @@ class CoopGen(Gen):
         # the wrapper left this wave's polynomial (zero for the mask polynomials, the rotated test vector for the body)
         # in its tile, natural order
         for m in range(16): self.ds_read("ds_read_b64", V(A3 + 2 * m, 2), L8T, offset=512 * m)
+        if self.neg_acc:         # the loop works on -acc (brgen.Gen)
+            for m in range(16): self.negate64(V(A3 + 2 * m, 2), CARRY[m % 4])
         e("v_mov_b32", R10, Lit(0))
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0
         e("s_mov_b32", SG.I, Lit(0))
@@ -273,7 +275,7 @@ class CoopGen(Gen):
         e("v_lshl_add_u32", R11, R11, Lit(3), SG.TILE)          # tile + (base & 63) * 8
         for m in range(16):
             t = T0.hi()
-            e("v_add_u32", t, Lit(m), R10)
+            e("v_add_u32", t, Lit(m + (16 if self.neg_acc else 0)), R10)      # (+ 16: the mask inverted, for the negated accumulator)
             e("v_bfe_i32", SGN3[m], t, Lit(4), Lit(1))          # 0 / -1: coefficient comes from the negated half
             e("v_and_b32", t, Lit(15), t)
             e("v_lshl_add_u32", RA3[m], t, Lit(9), R11)
@@ -375,7 +377,7 @@ class CoopGen(Gen):
             j = m + 8 * half
             x = V(v[m].i + 2 * half, 2)
             al, ah = V(A3 + 2 * j), V(A3 + 2 * j + 1)
-            self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k])
+            self.torus_add(x, al, ah, al, ah, tmp[k][0], tmp[k][1], CARRY[k], neg=self.neg_acc)
         chains = []
         for m in range(8):
             for half in range(2):
@@ -403,6 +405,7 @@ class CoopGen(Gen):
         e("v_lshlrev_b32", L8, Lit(3), LANE)                    # (register 9: the published-transform address is dead)
         e("v_add_u32", T0.lo(), Lit(4096), L8)
         for m in range(16):
+            if self.neg_acc: self.negate64(V(A3 + 2 * m, 2), CARRY[m % 4])       # back to acc
             self.gstore("global_store_dwordx2", L8 if m < 8 else T0.lo(), V(A3 + 2 * m, 2), SG.OUT, offset=512 * (m & 7))
         self.vm_wait_all()
         if self.stamps:

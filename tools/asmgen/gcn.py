@@ -400,6 +400,20 @@ class Emu:
         r = x - y - self._cget(ci).astype(np.int64)
         self.wr32(d, r.astype(np.uint64) & np.uint64(0xFFFFFFFF)); self._cset(co, r < 0)
 
+    def op_v_lshl_add_u64(self, d, a, sh, b):
+        """64-bit (a << sh) + b on register pairs (gfx940+): one 4-cycle instruction where v_add_co_u32 + v_addc_co_u32 are two"""
+        def rd(x):
+            assert isinstance(x, V) and x.n == 2, x
+            if self.pend_v[x.i] or self.pend_v[x.i + 1]: raise Poison("read of v[%d:%d] before its load was waited for" % (x.i, x.i + 1))
+            return self.v[x.i].astype(np.uint64) | (self.v[x.i + 1].astype(np.uint64) << np.uint64(32))
+        k = int(self.rd32(sh)[0]) & 63
+        assert k <= 4, "shift amounts above 4 are not defined for v_lshl_add_u64"
+        r = (rd(a) << np.uint64(k)) + rd(b)
+        assert isinstance(d, V) and d.n == 2
+        if self.pend_v[d.i] or self.pend_v[d.i + 1]: raise Poison("write to v[%d:%d] while a load into it is in flight" % (d.i, d.i + 1))
+        self.v[d.i] = (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        self.v[d.i + 1] = (r >> np.uint64(32)).astype(np.uint32)
+
     def op_v_mbcnt_lo_u32_b32(self, d, mask, add):
         m = int(self.rd32(mask)[0])
         cnt = np.array([bin(m & ((1 << min(l, 32)) - 1)).count("1") for l in range(64)], np.uint32)
