@@ -90,9 +90,9 @@ def test_generated_lut_tree_equals_oracle(oracle):
 
 
 def test_trace_loop_variants_are_the_same_arithmetic(oracle):
-    """the generator's alternatives kept for experiments: keys streamed by every wave instead of the shared ring, a
-    deeper ring, transforms without the spread exchange stores"""
-    for env in ({"TR_KEYS": "global"}, {"TR_SLOTS": "6"}, {"TR_PIPE": "0"}):
+    """the generator's alternatives kept for experiments: keys through the workgroup's shared LDS ring instead of streamed by
+    every wave (the default until round 4), a deeper ring, transforms without the spread exchange stores"""
+    for env in ({"TR_KEYS": "ring"}, {"TR_KEYS": "ring", "TR_SLOTS": "6"}, {"TR_PIPE": "0"}):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_trace.py"), "7"], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, **env))
         assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, str(env) + r.stdout + r.stderr

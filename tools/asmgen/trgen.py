@@ -208,12 +208,15 @@ class TraceGen(Gen):
             e("s_sleep", Lit(self.SKEW))
         self.p.label(lab)
 
-    # "ring": the workgroup's shared LDS ring (default); "global": every wave streams the key polynomials into registers
-    # itself.  Measured equal (14.1 ms standalone, any ring depth from 4 to 6 slots): streaming asks the CU's vector-memory
-    # path (64 B/clk) for 32 KiB per polynomial time, four times what the ring does, and is bound there; the ring by
-    # its per-polynomial issue costs.  Without any key loads the kernel takes 11.4 ms.  (Alternating the two - even
-    # polynomials through the ring, odd ones streamed - was slower than either: 14.7 ms.)
-    KEYS = os.environ.get("TR_KEYS", "ring")
+    # "global" (default since round 4): every wave streams the key polynomials into registers itself, three register sets;
+    # "ring": the workgroup's shared LDS ring (LDS-DMA fill, one s_barrier per polynomial).  Rounds 2-3 measured the two equal
+    # (14.1 ms standalone, any ring depth from 4 to 6 slots): streaming asks the CU's vector-memory path for 32 KiB per polynomial
+    # time, four times what the ring does, the ring pays its per-polynomial barrier and the LDS-DMA's landing rate.  With the
+    # rest of the loop faster (spread exchange stores, 64-bit adds) the streamed form is now ahead: 12.70 against 13.15 ms per
+    # launch in the pipeline, same box, alternating (profiles/r4ae_*); timing-only ablations of the ring form there: without the
+    # DMA 12.53, without the slot reads 12.25, without the barriers 11.95, without DMA and reads 10.93 ms.  (Alternating the two
+    # - even polynomials through the ring, odd ones streamed - was slower than either: 14.7 ms.)
+    KEYS = os.environ.get("TR_KEYS", "global")
 
     def key_load(self, j, dst):
         """key polynomial j of the current pass -> the eight quads dst (F-layout rows of 1 KiB, as the bootstrap key in brgen)"""
