@@ -322,9 +322,26 @@ class TraceGen(Gen):
                 e("s_mov_b32", brgen.ST_ACC[k].lo(), Lit(0)); e("s_mov_b32", brgen.ST_ACC[k].hi(), Lit(0))
             self.stamp(None)
 
-    def key_pass(self):
+    # TR_EARLY=1 (experiment, off): the first two key polynomials of a pass requested before the pass starts (under the body phase /
+    # under the last conversions).  Bit-identical; measured 12.72-12.87 against 12.58-12.76 ms per launch (same box, alternating):
+    # what a pass waits for at its start is not worth the vector-memory slots the early requests take from the other waves
+    EARLY = os.environ.get("TR_EARLY", "0") != "0"
+
+    def early_sets(self):
+        """Register sets in which the first two key polynomials of a pass can land before the pass starts: the accumulators of
+        columns 1 and 2 (P[1], P[2]) are not written before polynomials 1 and 2 are multiplied -- polynomial 0 (column 0) is read
+        from P[1] while F[0] = P[0] is started, polynomial 1 (column 1) from P[2] while F[1] = P[1] is started, and P[2] is
+        started by polynomial 2, which arrives through the ordinary sets."""
+        return [[quad(P[1], r) for r in range(8)], [quad(P[2], r) for r in range(8)]]
+
+    def key_prefetch(self, j):
+        """issue early polynomial j (0 or 1) of the pass whose base is in PB (streamed keys only)"""
+        if self.KEYS == "global" and self.EARLY: self.key_load(j, self.early_sets()[j])
+
+    def key_pass(self, early=False):
         """F[c] += D[j / 3] * key(j), j = 0..17, for the three columns c; D from the accumulation registers, the key
-        polynomials at PB + key_off(j).  Returns the quads of the three Fourier accumulators."""
+        polynomials at PB + key_off(j).  Returns the quads of the three Fourier accumulators.  early: polynomials 0 and 1 were
+        requested by key_prefetch before the pass."""
         e = self.e
         Fq = [[quad(P[c], r) for r in range(8)] for c in range(KP)]
         KS = [[quad(K[b], r) for r in range(8)] for b in range(2)]
@@ -356,10 +373,18 @@ class TraceGen(Gen):
             # barrier, no LDS traffic in the pass (418 cycles per polynomial against 485 through the ring and 175 of
             # arithmetic; the kernel as a whole takes the same time).
             KS = KS + [K2]
-            for j in range(3): self.key_load(j, KS[j % 3])
-            for j in range(NK):
-                macs(j, KS[j % 3])                           # e() waits for the polynomial's loads at their first use
-                if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
+            if early and self.EARLY:
+                # polynomials 0 and 1 are (nearly) there; 2, 3, 4 start now and land while 0 and 1 are multiplied
+                ES = self.early_sets()
+                for j in range(2, 5): self.key_load(j, KS[(j - 2) % 3])
+                for j in range(NK):
+                    macs(j, ES[j] if j < 2 else KS[(j - 2) % 3])
+                    if j >= 2 and j + 3 < NK: self.key_load(j + 3, KS[(j - 2) % 3])
+            else:
+                for j in range(3): self.key_load(j, KS[j % 3])
+                for j in range(NK):
+                    macs(j, KS[j % 3])                       # e() waits for the polynomial's loads at their first use
+                    if j + 3 < NK: self.key_load(j + 3, KS[j % 3])
         else:
             # Ring of four slots, one key polynomial per slot, DMA three polynomials ahead (a pair-wise ring with one
             # barrier per two polynomials was measured slower: one pair of lookahead does not cover the DMA latency).
@@ -430,6 +455,12 @@ class TraceGen(Gen):
                     for k in range(4):
                         e("v_accvgpr_write_b32", A(((q * AUTO_L + lev) * 8 + r) * 4 + k), V(polys[lev][r].i + k))
         self.stamp(0)
+        early0 = self.KEYS == "global" and self.EARLY
+        if early0:               # the first pass's first two key polynomials land under the body phase (P[1], P[2] are free: the transforms are parked)
+            e("s_mul_i32", TS.T, TS.IDX, Lit(2 * AUTO_L * KP * 512 * 16))
+            e("s_add_u32", TS.PB.lo(), TS.AUTO.lo(), TS.T)
+            e("s_addc_u32", TS.PB.hi(), TS.AUTO.hi(), Lit(0))
+            self.key_prefetch(0); self.key_prefetch(1)
         # ---- body: g[2] += g[2](X^t)   (reads of every word before the first write)
         self.c("---- body polynomial += its automorphism image")
         OWN = [V(K[0] + 2 * j, 2) for j in range(16)]
@@ -448,21 +479,25 @@ class TraceGen(Gen):
             self.merge([self.chain(body, j0 + k, k) for k in range(4)])
         self.stamp(1)
         # ---- two passes over the split key
-        for s_ in range(2):
-            self.c("---- key pass %d (split %s): F[c] += D[j / 3] * key(j), j = 0..17, keys through the ring" % (s_, "low 41 bits" if s_ == 0 else "high 23 bits"))
+        def pass_base(s_):
             # pass base pointer: auto_f + s * split_stride + idx * (2 * 3 * 3 * 512 * 16)
             e("s_mul_i32", TS.T, TS.IDX, Lit(2 * AUTO_L * KP * 512 * 16))
             if s_: e("s_add_u32", TS.T, TS.T, TS.SPLIT)
             e("s_add_u32", TS.PB.lo(), TS.AUTO.lo(), TS.T)
             e("s_addc_u32", TS.PB.hi(), TS.AUTO.hi(), Lit(0))
-            Fq = self.key_pass()
+        for s_ in range(2):
+            self.c("---- key pass %d (split %s): F[c] += D[j / 3] * key(j), j = 0..17" % (s_, "low 41 bits" if s_ == 0 else "high 23 bits"))
+            if not (self.KEYS == "global" and self.EARLY): pass_base(s_)       # (early mode: set where the pass's first two polynomials are requested)
+            Fq = self.key_pass(early=True)
             self.stamp(2)
             # ---- three inverse transforms together, then the accumulation into the GLWE
             xq = [quad(K[0], r) for r in range(8)] + [quad(K[1], r) for r in range(8)] + [quad(DC, r) for r in range(8)]
             Fq, spare = self.inv3(Fq, xq)
             self.stamp(3)
             self.c("---- g[c] += round(inverse)%s" % (" << 41" if s_ else ""))
-            for c in range(KP):
+            pre = s_ == 0 and self.KEYS == "global" and self.EARLY
+            if pre: pass_base(1)
+            for c in ((1, 2, 0) if pre else range(KP)):      # (columns 1 and 2 first: their registers take the next pass's first two key polynomials)
                 if s_ == 0:
                     CUR = [V(K[0] + 2 * j, 2) for j in range(16)]            # full words
                     for j in range(16): self.ds_read("ds_read_b64", CUR[j], L8T, offset=GL + c * 8192 + 512 * j)
@@ -495,6 +530,8 @@ class TraceGen(Gen):
                         chains.append(self.chain(upd, m, half, len(chains)))
                         if len(chains) == 4:
                             self.merge(chains); chains = []
+                if pre and c == 1: self.key_prefetch(0)
+                if pre and c == 2: self.key_prefetch(1)
             self.stamp(4)
         # ---- loop control
         self.lg_wait_all()
