@@ -632,23 +632,39 @@ class Gen:
     # ---------------------------------------------------------------- integer <-> double
     def digit_pair(self, q, own_lo, own_hi, sgn, t, cy=VCC):
         """q holds a rotated torus word in (q.i, q.i+1): replace it by the f64 digit of (+-word - own).
-        pbs_digit of tx_kernels.hpp (B = 23, one level, balanced top tie)."""
+        pbs_digit of tx_kernels.hpp (B = 23, one level, balanced top tie).  t: a temporary -- an aligned register PAIR selects the
+        short form below (negated accumulator only), a single register the five-instruction difference of rounds 2-3."""
         lo, hi = V(q.i), V(q.i + 1)
-        self.e("v_xor_b32", lo, lo, sgn)
-        self.e("v_xor_b32", hi, hi, sgn)
-        self.e("v_sub_co_u32", lo, cy, lo, sgn)
-        self.e("v_subb_co_u32", hi, cy, hi, sgn, cy)
-        if self.neg_acc:         # the words are those of -acc and sgn is the inverted mask: -+acc'[j + rot] + acc'[j]
-            assert own_hi.i == own_lo.i + 1 and own_lo.i % 2 == 0
-            self.e("v_lshl_add_u64", V(q.i, 2), V(q.i, 2), Lit(0), V(own_lo.i, 2))
+        short = self.neg_acc and t.n == 2
+        if short:
+            # The words are those of -acc and sgn is the inverted mask: d = acc'[j] +- acc'[j + rot], + where sgn = 0, - where
+            # sgn = -1.  x - y = ~(~x + y), so d = ((own ^ sgn) + word) ^ sgn: two xors into the temporary pair, ONE 64-bit add --
+            # and only the high dword of d is ever read (B = 23, one level), so the closing xor is that dword's alone and rides in
+            # the rounding add (v_xad_u32).  Seven instructions per word where the conditional negation (xor, xor, v_sub_co_u32,
+            # v_subb_co_u32: the carry forms cost 4 cycles each) + add + rounding add took nine: 8 cycles x 48 words per step.
+            assert own_hi.i == own_lo.i + 1 and own_lo.i % 2 == 0 and t.i % 2 == 0
+            self.e("v_xor_b32", t.lo(), own_lo, sgn)
+            self.e("v_xor_b32", t.hi(), own_hi, sgn)
+            self.e("v_lshl_add_u64", V(q.i, 2), t, Lit(0), V(q.i, 2))
+            t = t.lo()
         else:
-            self.e("v_sub_co_u32", lo, cy, lo, own_lo)
-            self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
+            if t.n == 2: t = t.lo()
+            self.e("v_xor_b32", lo, lo, sgn)
+            self.e("v_xor_b32", hi, hi, sgn)
+            self.e("v_sub_co_u32", lo, cy, lo, sgn)
+            self.e("v_subb_co_u32", hi, cy, hi, sgn, cy)
+            if self.neg_acc:         # the words are those of -acc and sgn is the inverted mask: -+acc'[j + rot] + acc'[j]
+                assert own_hi.i == own_lo.i + 1 and own_lo.i % 2 == 0
+                self.e("v_lshl_add_u64", V(q.i, 2), V(q.i, 2), Lit(0), V(own_lo.i, 2))
+            else:
+                self.e("v_sub_co_u32", lo, cy, lo, own_lo)
+                self.e("v_subb_co_u32", hi, cy, hi, own_hi, cy)
         # digit = sext23(((hi + 0x100) >> 9) - e) + e with e = 1 on even coefficient indices (= even lanes), 0 on odd ones: the tie
         # 2^22 goes to +B/2 there and to -B/2 here.  Three instructions (round 4; five before): EREG holds 0x100 - (e << 9), so one
         # add rounds and shifts the tie, an arithmetic shift right by 9 of the 32-bit word IS the sign-extended 23-bit field, and
         # "+ e" is the carry-in of a v_addc_co_u32 whose carry mask is vcc = the even lanes (set once in the prologue)
-        self.e("v_add_u32", t, hi, EREG)
+        if short: self.e("v_xad_u32", t, hi, sgn, EREG)
+        else: self.e("v_add_u32", t, hi, EREG)
         self.e("v_ashrrev_i32", t, Lit(9), t)
         self.e("v_addc_co_u32", t, cy, t, Lit(0), VCC)
         self.e("v_cvt_f64_i32", V(q.i, 2), t)
@@ -803,7 +819,7 @@ class Gen:
         self.c("---- rotation: stage mask polynomials in the tile, gather rotated coefficients")
         xq = [quad(X, r) for r in range(12)]
         OWN = [V(X + 2 * j, 2) for j in range(16)]              # body words of this lane
-        temps = [T0.lo(), T0.hi(), T1.lo(), T1.hi()]
+        temps = [T0, T1, V(X + 32, 2), V(X + 34, 2)] if os.environ.get("BR_DIGIT", "short") == "short" else [T0.lo(), T0.hi(), T1.lo(), T1.hi()]   # X8, the spare quad, is idle here
 
         def lds_traffic(q):
             if q < 2:

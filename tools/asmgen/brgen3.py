@@ -316,7 +316,7 @@ class CoopGen(Gen):
             self.ds_read("ds_read_b64", V(D3 + 4 * m, 2), RA3[m])
             self.ds_read("ds_read_b64", V(D3 + 4 * m + 2, 2), RA3[m + 8])
         self.c("---- digits: ct1 = acc X^rot - acc, one level (B = 23), as f64")
-        temps = [T0.lo(), T0.hi(), T1.lo(), T1.hi()]
+        temps = [T0, T1, V(X3, 2), V(X3 + 2, 2)] if os.environ.get("BR_DIGIT", "short") == "short" else [T0.lo(), T0.hi(), T1.lo(), T1.hi()]   # the ring's quad 0 is idle here
         chains = []
         for m in range(8):
             for half in range(2):

@@ -343,6 +343,7 @@ class Emu:
     def op_v_lshrrev_b32(self, d, a, b): self.wr32(d, self.rd32(b) >> (self.rd32(a) & 31))
     def op_v_lshl_add_u32(self, d, a, b, c): self.wr32(d, (self.rd32(a) << (self.rd32(b) & 31)) + self.rd32(c))
     def op_v_add3_u32(self, d, a, b, c): self.wr32(d, self.rd32(a) + self.rd32(b) + self.rd32(c))
+    def op_v_xad_u32(self, d, a, b, c): self.wr32(d, (self.rd32(a) ^ self.rd32(b)) + self.rd32(c))
 
     def op_v_ashrrev_i32(self, d, a, b):
         self.wr32(d, (self.rd32(b).view(np.int32) >> (self.rd32(a) & 31).astype(np.int32)).view(np.uint32))
