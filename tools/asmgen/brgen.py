@@ -108,6 +108,10 @@ class Gen:
         # negation on the source modifiers of the rounding's first two operations.  The polynomials are negated once on the way in
         # and once on the way out (per unit, outside the loop).  Same integers mod 2^64 at every step: bit-identical.
         self.neg_acc = True
+        # e_reg: VGPR 4 holds e = 1 on even lanes (digit_pair's "+ e" is then a plain v_add_u32: 2 cycles where the carry-in form
+        # took 4).  The register was lane * 16 + 4096, the offset of key rows 4..7: the key pointers are biased by 4096 instead and
+        # all eight rows use lane * 16 with immediate offsets -4096 .. 3072
+        self.e_reg = V(4) if os.environ.get("BR_EREG", "1") == "1" else None
 
     # ---------------------------------------------------------------- emission + counters
     # Every emitted instruction goes through e(): registers it touches that are the destination of a load still in
@@ -630,6 +634,13 @@ class Gen:
         return polys, spare
 
     # ---------------------------------------------------------------- integer <-> double
+    def key_bias(self): return 4096 if self.e_reg is not None else 0
+
+    def key_quad(self, dst, r, ptr):
+        """load row r (0..7: 64 complex = 1 KiB) of the key polynomial at ptr (biased by key_bias()) into the quad dst"""
+        if self.e_reg is not None: self.gload("global_load_dwordx4", dst, L16, ptr, offset=(r - 4) * 1024)
+        else: self.gload("global_load_dwordx4", dst, L16 if r < 4 else OFF1, ptr, offset=(r & 3) * 1024)
+
     def digit_pair(self, q, own_lo, own_hi, sgn, t, cy=VCC):
         """q holds a rotated torus word in (q.i, q.i+1): replace it by the f64 digit of (+-word - own).
         pbs_digit of tx_kernels.hpp (B = 23, one level, balanced top tie).  t: a temporary -- an aligned register PAIR selects the
@@ -666,7 +677,8 @@ class Gen:
         if short: self.e("v_xad_u32", t, hi, sgn, EREG)
         else: self.e("v_add_u32", t, hi, EREG)
         self.e("v_ashrrev_i32", t, Lit(9), t)
-        self.e("v_addc_co_u32", t, cy, t, Lit(0), VCC)
+        if self.e_reg is not None: self.e("v_add_u32", t, t, self.e_reg)
+        else: self.e("v_addc_co_u32", t, cy, t, Lit(0), VCC)
         self.e("v_cvt_f64_i32", V(q.i, 2), t)
 
     def torus_add(self, x, cur_lo, cur_hi, dst_lo, dst_hi, tA, tB, cy=VCC, neg=False):
@@ -703,7 +715,7 @@ class Gen:
         e("v_lshl_add_u32", L8T, LANE, Lit(3), SG.TILE)
         e("v_lshl_add_u32", L16T, LANE, Lit(4), SG.TILE)
         e("v_lshlrev_b32", L16, Lit(4), LANE)
-        e("v_add_u32", OFF1, Lit(4096), L16)
+        if self.e_reg is None: e("v_add_u32", OFF1, Lit(4096), L16)
         e("v_and_b32", T0.lo(), Lit(7), LANE)                   # b
         e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
         e("v_add_u32", TWBA, Lit(TWB), TWBA)
@@ -721,6 +733,7 @@ class Gen:
         e("v_and_b32", T0.lo(), Lit(1), LANE)
         e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
         e("v_add_u32", EREG, Lit(-0x100), EREG)
+        if self.e_reg is not None: e("v_xor_b32", self.e_reg, Lit(1), T0.lo())
         self.even_lanes_to_vcc()
         if self.fair:
             e("v_mov_b32", PARTNER, Lit(0))
@@ -803,12 +816,12 @@ class Gen:
 
         def key_ptrs(col):
             for q in range(3):
-                e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192))
+                e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit((q * 3 + col) * 8192 + self.key_bias()))
                 e("s_addc_u32", kps[q].hi(), SG.ROW.hi(), Lit(0))
 
         def issue(col, k):
             q, r = stream[k]
-            self.gload("global_load_dwordx4", ring_of(col)[k % NG], L16 if r < 4 else OFF1, kps[q], offset=(r & 3) * 1024)
+            self.key_quad(ring_of(col)[k % NG], r, kps[q])
 
         def early(col, lo=0, hi=EARLY):
             self.c("key ring: elements %d..%d of column %d, issued ahead of their use" % (lo, hi - 1, col))

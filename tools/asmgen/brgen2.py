@@ -47,6 +47,7 @@ ABL2 = os.environ.get("BR2_ABL", "")     # timing-only ablations (B no barriers,
 class PairGen(brgen3.CoopGen):
     def __init__(self, role):
         super().__init__(stamps=False, prio="")
+        self.e_reg = None                     # (this experiment keeps lane * 16 + 4096 in v4 and the carry-in form of the digit)
         self.neg_acc = False          # (this experiment keeps the accumulator as it was built: its own prologues / epilogues)
         assert role in "AB"
         self.role = role

@@ -138,7 +138,7 @@ class CoopGen(Gen):
         e("v_lshl_add_u32", L16T, LANE, Lit(4), SG.TILE)
         e("v_lshl_add_u32", L16T0, LANE, Lit(4), TILE0)
         e("v_lshlrev_b32", L16, Lit(4), LANE)
-        e("v_add_u32", OFF1, Lit(4096), L16)
+        if self.e_reg is None: e("v_add_u32", OFF1, Lit(4096), L16)
         e("v_and_b32", T0.lo(), Lit(7), LANE)                   # b
         e("v_lshlrev_b32", TWBA, Lit(4), T0.lo())
         e("v_add_u32", TWBA, Lit(brgen.TWB), TWBA)
@@ -153,6 +153,7 @@ class CoopGen(Gen):
         e("v_and_b32", T0.lo(), Lit(1), LANE)
         e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
         e("v_add_u32", EREG, Lit(-0x100), EREG)
+        if self.e_reg is not None: e("v_xor_b32", self.e_reg, Lit(1), T0.lo())
         self.even_lanes_to_vcc()
         for name, val in (("C_2M64", 2.0 ** -64), ("C_M2P64", -(2.0 ** 64)), ("C_84", 1.5 * 2.0 ** 84), ("C_52", 1.5 * 2.0 ** 52),
                           ("C_SQH", 0.70710678118654752440)):
@@ -298,13 +299,13 @@ class CoopGen(Gen):
 
         def issue(k):
             q, r = stream[k]
-            self.gload("global_load_dwordx4", ring[k % NG], L16 if r < 4 else OFF1, kps[q], offset=(r & 3) * 1024)
+            self.key_quad(ring[k % NG], r, kps[q])
 
         def early(lo, hi):
             self.c("key ring: elements %d..%d, issued ahead of their use" % (lo, hi - 1))
             if lo == 0:
                 for q in range(3):       # ROW points at column c of row i: key[q][c] is q * 3 polynomials further
-                    e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit(q * 3 * 8192))
+                    e("s_add_u32", kps[q].lo(), SG.ROW.lo(), Lit(q * 3 * 8192 + self.key_bias()))
                     e("s_addc_u32", kps[q].hi(), SG.ROW.hi(), Lit(0))
             for k in range(lo, hi): issue(k)
         early(0, 3)
