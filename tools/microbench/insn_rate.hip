@@ -26,6 +26,22 @@ __global__ void k_rate(unsigned long long *out, int iters)
         } else if (KIND == 3) { // v_permlane32_swap
             asm volatile(REP64("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n")
                          : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+        } else if (KIND == 5) { // v_lshlrev_b64 (variable shift)
+            asm volatile(REP64("v_lshlrev_b64 %0, %4, %0\n v_lshlrev_b64 %1, %4, %1\n v_lshlrev_b64 %2, %4, %2\n v_lshlrev_b64 %3, %4, %3\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(threadIdx.x & 1u));
+        } else if (KIND == 6) { // v_and_or_b32, v_xad_u32, v_max_u32, v_bfe_u32 (one each)
+            asm volatile(REP64("v_and_or_b32 %0, %0, %4, %1\n v_xad_u32 %1, %1, %4, %2\n v_max_u32 %2, %2, %3\n v_bfe_u32 %3, %0, 3, 11\n")
+                         : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1) : "v"(threadIdx.x * 77u + 1u));
+        } else if (KIND == 7) { // v_fma_f64 x 2 + v_add_u32 x 2: do 32-bit operations hide behind FP64 ones?
+            double x = __longlong_as_double(a), y = __longlong_as_double(b);
+            asm volatile(REP64("v_fma_f64 %0, %0, %4, %0\n v_add_u32 %2, %2, %5\n v_fma_f64 %1, %1, %4, %1\n v_add_u32 %3, %3, %5\n")
+                         : "+v"(x), "+v"(y), "+v"(lo0), "+v"(hi0) : "v"(1.0), "v"(threadIdx.x * 77u + 1u));
+            a = __double_as_longlong(x); b = __double_as_longlong(y);
+        } else if (KIND == 8) { // v_cvt_f64_i32 / v_rndne_f64 / v_mul_f64 / v_fma_f64 (one each)
+            double x = __longlong_as_double(a), y = __longlong_as_double(b), z = __longlong_as_double(c);
+            asm volatile(REP64("v_cvt_f64_i32 %0, %3\n v_rndne_f64 %1, %1\n v_mul_f64 %2, %2, %4\n v_fma_f64 %1, %1, %4, %0\n")
+                         : "+v"(x), "+v"(y), "+v"(z), "+v"(lo0) : "v"(1.0));
+            a = __double_as_longlong(x); b = __double_as_longlong(y); c = __double_as_longlong(z);
         } else if (KIND == 4) { // v_add_u32 (32-bit reference)
             asm volatile(REP64("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
                          : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1) : "v"(threadIdx.x * 77u + 1u));
@@ -56,6 +72,11 @@ template <int KIND> void run(const char *name, int threads)
 }
 int main()
 {
+    for (int threads : {256, 512, 768}) {
+        if (threads == 256) { run<5>("v_lshlrev_b64", 256); run<6>("and_or/xad/max/bfe", 256); run<7>("fma_f64 + add_u32 mix", 256); run<8>("cvt/rndne/mul/fma f64", 256); }
+        if (threads == 512) { run<5>("v_lshlrev_b64", 512); run<6>("and_or/xad/max/bfe", 512); run<7>("fma_f64 + add_u32 mix", 512); run<8>("cvt/rndne/mul/fma f64", 512); }
+        if (threads == 768) { run<5>("v_lshlrev_b64", 768); run<6>("and_or/xad/max/bfe", 768); run<7>("fma_f64 + add_u32 mix", 768); run<8>("cvt/rndne/mul/fma f64", 768); }
+    }
     for (int threads : {256, 512, 768, 1024}) {
         if (threads == 256) { run<2>("v_add_f64", 256); run<4>("v_add_u32", 256); run<0>("v_lshl_add_u64", 256); run<1>("v_add_co + v_addc_co", 256); run<3>("v_permlane32_swap_b32", 256); }
         if (threads == 512) { run<2>("v_add_f64", 512); run<4>("v_add_u32", 512); run<0>("v_lshl_add_u64", 512); run<1>("v_add_co + v_addc_co", 512); run<3>("v_permlane32_swap_b32", 512); }
