@@ -373,9 +373,12 @@ class Gen:
                     if k + 1 < len(jobs): chains.append(self.chain(self.cmul_w, *jobs[k + 1], T1))
                 self.merge(chains)
 
-    def dft8(self, v, spare, sign):
+    def dft8(self, v, spare, sign, home=None):
         """8-point DFT of the complex values in quads v[0..7] (dft8<sign> of tx_device.hpp, same pairing).
-        Returns (list of quads holding outputs 0..7, the new spare quad)."""
+        Returns (list of quads holding outputs 0..7, the new spare quad).  home = (lo, hi): a pass that no exchange follows --
+        the quad outside registers lo..hi-1 (the spare on entry) must be the free one on exit: the last butterfly is then the
+        one whose first operand sits in it, written as (sum -> spare, difference -> the second operand's quad), which frees
+        it (round 4: this took two v_mov_b64 per transform before; same operations, same operands, another destination)."""
         tmp = T0
         a, b = [None] * 4, [None] * 4
         for i in range(4):
@@ -412,19 +415,42 @@ class Gen:
             self.e("v_fma_f64", qim(x.q), y.im, c, x.im)
             return Cx.of(x.q), Cx.of(spare), y.q
 
-        def four(x0, x1, x2, x3, o0, o1, o2, o3, spare, scaled=False):
+        def foreign(q): return home is not None and not (home[0] <= q.i < home[1])
+
+        def last_free_x(x, y, spare, scaled):
+            """(x, y) -> (x + [c] y in `spare`, x - [c] y in y's quad); frees x's quad.  y must be a plain view of its quad."""
+            assert y.q is not None and not y.re.neg and not y.im.neg and y.re.i == qre(y.q).i and y.im.i == qim(y.q).i
+            if scaled:
+                self.e("v_fma_f64", qre(spare), y.re, c, x.re)
+                self.e("v_fma_f64", qim(spare), y.im, c, x.im)
+                self.e("v_fma_f64", qre(y.q), -y.re, c, x.re)
+                self.e("v_fma_f64", qim(y.q), -y.im, c, x.im)
+            else:
+                self.cadd_to(spare, x, y)
+                self.csub_to(y.q, x, y)
+            return Cx.of(spare), Cx.of(y.q), x.q
+
+        def four(x0, x1, x2, x3, o0, o1, o2, o3, spare, scaled=False, final=False):
             # p0 = x0 + x2; q0 = x0 - x2; p1 = x1 + x3; d = x1 - x3; q1 = +-i d; o0 = p0 + p1; o1 = p0 - p1; o2 = q0 + q1; o3 = q0 - q1
             # (scaled: the last four use c p1 and c q1)
             p0, q0, fr = self.bfly(x0, x2, spare); spare = fr
             p1, d, fr = self.bfly(x1, x3, spare); spare = fr
             q1 = d.mul_i() if sign > 0 else d.mul_mi()
             last = bfly_scaled if scaled else self.bfly
-            r0, r1, fr = last(p0, p1, spare); spare = fr
-            r2, r3, fr = last(q0, q1, spare); spare = fr
+            if final and foreign(p0.q):          # the foreign quad holds p0: (q0, q1) first, then (p0, p1) with p0's quad freed
+                r2, r3, fr = last(q0, q1, spare); spare = fr
+                r0, r1, fr = last_free_x(p0, p1, spare, scaled); spare = fr
+            else:
+                r0, r1, fr = last(p0, p1, spare); spare = fr
+                r2, r3, fr = last(q0, q1, spare); spare = fr
             out[o0], out[o1], out[o2], out[o3] = r0.q, r1.q, r2.q, r3.q
             return spare
-        spare = four(a[0], a[1], a[2], a[3], 0, 4, 2, 6, spare)
-        spare = four(b[0], u1, t2, u3, 1, 5, 3, 7, spare, scaled=True)
+        if foreign(a[0].q):           # (a layout whose spare lies below the home region: the foreign quad came in as v[0])
+            spare = four(b[0], u1, t2, u3, 1, 5, 3, 7, spare, scaled=True)
+            spare = four(a[0], a[1], a[2], a[3], 0, 4, 2, 6, spare, final=True)
+        else:
+            spare = four(a[0], a[1], a[2], a[3], 0, 4, 2, 6, spare)
+            spare = four(b[0], u1, t2, u3, 1, 5, 3, 7, spare, scaled=True, final=True)
         return out, spare
 
     def home(self, v, spare, lo, hi):
@@ -565,7 +591,7 @@ class Gen:
         if before_pass3: before_pass3()            # the twiddle quads xq[0..7] are free from here on
         for p in range(3):
             self.lg_wait(set().union(*[self.regs(q) for q in polys[p]]))
-            polys[p], spare = self.dft8(polys[p], spare, +1)
+            polys[p], spare = self.dft8(polys[p], spare, +1, home=(home_lo[p], home_lo[p] + 32))
             polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
         self.substamp("fwd3", 3)
         return polys, spare
@@ -593,7 +619,7 @@ class Gen:
         self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
         self.cmul_all([(v[r], tw[r]) for r in range(8)], spare, conj=True)
         home_lo = min(q.i for q in v)
-        v, spare = self.dft8(v, spare, -1)
+        v, spare = self.dft8(v, spare, -1, home=(home_lo, home_lo + 32))
         v, spare = self.home(v, spare, home_lo, home_lo + 32)
         self.twist_consts([v], spare, conj=True)
         return v, spare
@@ -626,7 +652,7 @@ class Gen:
         self.substamp("inv3", 1)
         for p in range(3):
             self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spare, conj=True)
-            polys[p], spare = self.dft8(polys[p], spare, -1)
+            polys[p], spare = self.dft8(polys[p], spare, -1, home=(home_lo[p], home_lo[p] + 32))
             polys[p], spare = self.home(polys[p], spare, home_lo[p], home_lo[p] + 32)
         self.substamp("inv3", 2)
         self.twist_consts(polys, spare, conj=True)

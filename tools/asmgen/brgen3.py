@@ -101,7 +101,7 @@ class CoopGen(Gen):
         v, spare = self.xchg_lo(v, spare)
         self.c("forward: pass 3 (dft8)")
         if before_pass3: before_pass3()            # the twiddle quads xq[0..7] are free from here on
-        v, spare = self.dft8(v, spare, +1)
+        v, spare = self.dft8(v, spare, +1, home=(home_lo, home_lo + 32))
         v, spare = self.home(v, spare, home_lo, home_lo + 32)
         return v, spare
 
@@ -122,7 +122,7 @@ class CoopGen(Gen):
         self.c("inverse: pass 1' (pass-A twiddles conj, dft8, untwist constants)")
         self.cmul_all([(v[r], tw[r]) for r in range(8)], spare, conj=True)
         home_lo = min(q.i for q in v)
-        v, spare = self.dft8(v, spare, -1)
+        v, spare = self.dft8(v, spare, -1, home=(home_lo, home_lo + 32))
         v, spare = self.home(v, spare, home_lo, home_lo + 32)
         self.twist_consts([v], spare, conj=True)
         return v, spare

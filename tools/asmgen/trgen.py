@@ -103,7 +103,7 @@ class TraceGen(Gen):
                     self.cmul_all([(polys[p][r], tw[r - 1]) for r in range(1, 8)], spares[p], conj=True)
                     if p == 2: self.load_tw(tw, 0, 8)               # the pass-A rows replace the pass-B rows after their last use
                 if pas == 1: self.cmul_all([(polys[p][r], tw[r]) for r in range(8)], spares[p], conj=True)
-                polys[p], spares[p] = self.dft8(polys[p], spares[p], -1)
+                polys[p], spares[p] = self.dft8(polys[p], spares[p], -1, home=(home_lo[p], home_lo[p] + 32) if pas == 1 else None)
                 if pas == 1: polys[p], spares[p] = self.home(polys[p], spares[p], home_lo[p], home_lo[p] + 32)
                 if pas == 2 and self.xhi_regs: polys[p], spares[p] = self.xchg_hi_regs(polys[p], spares[p])
             return f
@@ -140,7 +140,7 @@ class TraceGen(Gen):
 
         def valu(pas, p):
             def f():
-                polys[p], spares[p] = self.dft8(polys[p], spares[p], +1)
+                polys[p], spares[p] = self.dft8(polys[p], spares[p], +1, home=(home_lo[p], home_lo[p] + 32) if pas == 3 else None)
                 if pas == 1:
                     self.cmul_all([(polys[p][r], tw[r]) for r in range(8)])
                     if p == 2: self.load_tw(tw, 0, 7, compact=True)
