@@ -127,30 +127,37 @@ __device__ __forceinline__ void fmac8r(cplx (&acc)[8], const cplx (&d)[8], const
 // P consecutive decomposition levels (finest of the group first) of one row: digits -> f64,
 // transformed together, then accumulated against the key: F[c] += D[i] * key[lev(i)][c], for fixed c
 // in increasing i (the oracle's order: row outer, level finest-first inner).  Key loads are
-// software-pipelined one polynomial ahead.  lev0 = level index (0 = level 1) of the group's first digit.
+// software-pipelined MAC_DEPTH polynomials ahead (2: 16 KB in flight per wave; the LUT tree's multiply-accumulate waits for the
+// GGSW rows, one wave per SIMD -- 2.74 -> 2.55 ms per launch of 1024 bytes x 3 tables; 3 ahead spills), the first of them
+// in flight during the forward transforms (two there spill as well).  lev0 = level index (0 = level 1) of the group's first digit.
 // transform P digit polynomials (already f64) and accumulate them against key polynomials
 // key[(lev0 - i) * lev_stride + c * col_stride], i = 0..P-1
+#ifndef MAC_DEPTH
+#define MAC_DEPTH 2
+#endif
+#ifndef MAC_EARLY
+#define MAC_EARLY 1
+#endif
 template <int P, int NCOL>
 __device__ __forceinline__ void mac_group(cplx (&F)[NCOL][8], cplx (&d)[P][8], int lev0, const cplx *key,
                                           size_t lev_stride, size_t col_stride, const WaveCtx &w)
 {
-    cplx g[8];
-    load_key8(g, key + (size_t)lev0 * lev_stride, w.lane);
+    constexpr int T = P * NCOL, DEPTH = MAC_DEPTH;          // key polynomials of the group; how many are requested ahead of the one in use
+    cplx g[DEPTH + 1][8];
+    // polynomial j = (i, c) = (j / NCOL, j % NCOL): level lev0 - i, column c
+#pragma unroll
+    for (int j = 0; j < MAC_EARLY && j < DEPTH && j < T; j++)        // in flight during the forward transforms
+        load_key8(g[j % (DEPTH + 1)], key + (size_t)(lev0 - j / NCOL) * lev_stride + (size_t)(j % NCOL) * col_stride, w.lane);
     fft_fwd_n<P>(d, w.tw, w.tile, w.lane);
 #pragma unroll
-    for (int i = 0; i < P; i++)
+    for (int j = MAC_EARLY; j < DEPTH && j < T; j++)
+        load_key8(g[j % (DEPTH + 1)], key + (size_t)(lev0 - j / NCOL) * lev_stride + (size_t)(j % NCOL) * col_stride, w.lane);
 #pragma unroll
-        for (int c = 0; c < NCOL; c++) {
-            cplx gn[8];
-            const bool last = (i == P - 1) && (c == NCOL - 1);
-            const int ni = (c + 1 < NCOL) ? i : i + 1, nc = (c + 1 < NCOL) ? c + 1 : 0;
-            if (!last) load_key8(gn, key + (size_t)(lev0 - ni) * lev_stride + (size_t)nc * col_stride, w.lane);
-            fmac8r(F[c], d[i], g);
-            if (!last) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) g[r] = gn[r];
-            }
-        }
+    for (int j = 0; j < T; j++) {
+        const int n = j + DEPTH;
+        if (n < T) load_key8(g[n % (DEPTH + 1)], key + (size_t)(lev0 - n / NCOL) * lev_stride + (size_t)(n % NCOL) * col_stride, w.lane);
+        fmac8r(F[j % NCOL], d[j / NCOL], g[j % (DEPTH + 1)]);
+    }
 }
 template <int B, int L, int P, int NCOL, typename ST>
 __device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], ST (&shi)[8], int lev0,
