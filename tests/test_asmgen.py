@@ -25,6 +25,18 @@ def test_fair_variant_is_the_same_arithmetic_on_both_priority_paths(oracle):
         assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
+def test_digit_forms_are_the_same_arithmetic(oracle):
+    """the rotated difference of rounds 2-3 (conditional negation with the carry forms, nine instructions per word) and the digit's
+    carry-in add (e as the even-lane mask in vcc) stay generator options next to the seven-instruction form: same values"""
+    for env in ({"BR_DIGIT": "long"}, {"BR_EREG": "0"}, {"BR_DIGIT": "long", "BR_EREG": "0"}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate.py"), "2", "9"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, str(env) + r.stdout + r.stderr
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate3.py"), "2", "9"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, str(env) + r.stdout + r.stderr
+
+
 def test_cooperative_loop_equals_oracle_three_waves(oracle):
     """tools/asmgen/brgen3.py (k_blind_rotate6: three waves per unit, one per polynomial): a workgroup of three emulated
     waves sharing the LDS image and meeting at both barriers of every step, scheduled in both orders between barriers,
