@@ -147,6 +147,20 @@ def test_partial_schedule_bit_identical_full_parameters(rig768):
     assert np.array_equal(r.eng.transcipher_partial(ct, 1), r.octx.transcipher_partial(r.luts, ct, 1))
 
 
+def test_repeat_runs_are_bit_identical(rig768):
+    """the kernels' wave priorities, the fair tables (keyed by hardware CU ids, reused across launches with an epoch) and the dispatch by
+    launch size may change timing, never results: the same ciphertexts through the full schedule three times, ECB and CTR, sizes that
+    take k_blind_rotate6 (1 block) and k_blind_rotate7 / 5 (8 blocks: 1024 units, then the shared round's smaller launch)"""
+    r = rig768
+    rng = np.random.default_rng(77)
+    for nb in (1, 8):
+        ct = rng.integers(0, 256, 16 * nb, dtype=np.uint8).tobytes()
+        for kw in ({}, {"iv": bytes(range(16))}):
+            first = np.array(r.eng.transcipher(ct, **kw), copy=True)
+            for _ in range(2):
+                assert np.array_equal(first, r.eng.transcipher(ct, **kw))
+
+
 def test_toy_instance_full_cipher_matches_oracle_and_cleartext(rig768):
     """BASELINE config 1 at full parameters: ciphertext-level parity and plaintext exactness"""
     r = rig768
