@@ -37,6 +37,20 @@ BR_STREAM = os.path.join(ROOT, "temp-fhe-transciphering_amd", "csrc", "tx_br_asm
 BR_F64_FLOP_PER_UNIT_STEP = 64 * (984 + 312 + 2 * 744)
 
 
+def vector_instructions_per_unit_step(stream=BR_STREAM):
+    """vector (VALU) instructions of one pass through the generated CMux loop of k_blind_rotate5, counted in the instruction stream of
+    this tree: the lines between the loop's label and its backward branch that start with v_.  The loop's time follows this count
+    (every vector instruction of its mix costs 4 cycles, profiles/r4ai_*), so count x 4 cycles x unit-steps / (SIMDs x time x clock) is
+    the fraction of the vector pipe's issue slots the kernel uses."""
+    try: lines = open(stream).read().split("\n")
+    except OSError: return None
+    labels = [i for i, l in enumerate(lines) if "L_step" in l and ":" in l]
+    back = [i for i, l in enumerate(lines) if "s_cbranch" in l and "L_step" in l]
+    if not labels or not back: return None
+    body = lines[labels[0]:back[-1]]
+    return sum(1 for l in body if l.lstrip().lstrip('"').lstrip().startswith("v_"))
+
+
 def roofline_inputs(path=ROOFLINE_INPUTS, stream=BR_STREAM):
     """{key: entry} of profiles/roofline_inputs.json whose recorded sha256 is that of the instruction stream in this tree"""
     try:
@@ -403,6 +417,7 @@ def main(argv=None):
         # only the distinct state columns): algorithmic bytes of all of them over the time of all of them
         achieved = br_launch_bytes(t_units, args.n, t_launches) / (t_ms * 1e-3) / 1e9
         br_flops = t_units * args.n * BR_F64_FLOP_PER_UNIT_STEP
+        vips = vector_instructions_per_unit_step()
         # counter-derived figures: only from profiles/roofline_inputs.json, only when measured on this tree's instruction stream
         # and on this launch mix (the entry states the average units per launch its CSV covers)
         rin = roofline_inputs() if (args.n == 768 and br_kernel == "k_blind_rotate5") else {}
@@ -434,6 +449,9 @@ def main(argv=None):
                          "path_algorithmic_GBps": path_gbps, "path_frac": path_gbps / HBM_PEAK_GBS,
                          "fp64_valu": {"achieved_TFLOPs": br_flops / (t_ms * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
                                        "frac": br_flops / (t_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "vector_issue": (None if not (vips and br_kernel == "k_blind_rotate5") else
+                                          {"instructions_per_unit_and_step": vips, "cycles_per_instruction": 4, "simds": 1024, "nominal_clock_GHz": 2.4,
+                                           "frac_at_nominal_clock": vips * 4.0 * t_units * args.n / (1024 * t_ms * 1e-3 * 2.4e9)}),
                          "vector_pipe_busy_pmc": (vb["value"] if vb else None),
                          "vector_pipe_busy_source": (vb["source"] if vb else None),
                          "note": "the path is f64 transform arithmetic, not a stream: HBM fraction is low by construction; "
@@ -441,7 +459,9 @@ def main(argv=None):
                                  "(the CTR schedule's shared second round materialises fewer) over the step time; "
                                  "fp64_valu counts FP64 flops against the FMA peak at the nominal clock (half of this loop's FP64 "
                                  "instructions are adds, a fifth of its vector instructions 32-bit, and the chip runs it at "
-                                 "1.85-1.9 GHz: power-bound); vector_pipe_busy_pmc is the fraction of cycles a SIMD's vector pipe "
+                                 "2.1-2.2 GHz: power-limited, profiles/r4ar_*); vector_issue counts the loop's vector instructions in the "
+                                 "stream of this tree at 4 cycles each against the SIMDs' issue slots at the nominal clock (the bound the "
+                                 "loop's time follows); vector_pipe_busy_pmc is the fraction of cycles a SIMD's vector pipe "
                                  "executes an instruction (SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES); traffic and "
                                  "vector_pipe_busy_pmc come from profiles/roofline_inputs.json and are null unless they were "
                                  "measured on this tree's instruction stream and this launch mix"},

@@ -124,3 +124,16 @@ def test_bench_without_a_gpu_fails_fast_with_one_line():
     assert r.returncode != 0 and time.time() - t0 < 120
     assert ("no HIP device" in r.stderr) or ("need 8 GPUs" in r.stderr)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_vector_instruction_count_comes_from_the_stream(tmp_path):
+    """bench.py's vector_issue figure counts the v_ instructions of the generated CMux loop in the tree's instruction stream (between
+    the loop label and its backward branch), nothing typed in: a synthetic stream gives its own count, the real one a plausible one"""
+    b = load_bench()
+    f = tmp_path / "s.inc"
+    f.write_text('"  v_mov_b32 v0, 0\\n"\n"L_step%=:\\n"\n"  v_add_f64 v[0:1], v[2:3], v[4:5]\\n"\n"  s_nop 0\\n"\n"  ds_read_b64 v[0:1], v2\\n"\n'
+                 '"  v_xad_u32 v1, v2, v3, v4\\n"\n"  s_cbranch_scc1 L_step%=\\n"\n"  v_mov_b32 v9, 0\\n"\n')
+    assert b.vector_instructions_per_unit_step(str(f)) == 2
+    assert b.vector_instructions_per_unit_step(str(tmp_path / "missing.inc")) is None
+    n = b.vector_instructions_per_unit_step()
+    assert 2000 < n < 3500
