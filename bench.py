@@ -137,7 +137,7 @@ def parse_args(argv=None):
                          "averages of the command")
     ap.add_argument("--no-ctr-share", action="store_true",
                     help="CTR mode: bootstrap every state column of the second round, also those that hold the same ciphertexts "
-                         "in every block of the batch (TX_CTR_SHARE=0; same results, for A/B timing)")
+                         "in every block of the batch (tx_set_ctr_column_sharing(c, 0); same results, for A/B timing)")
     ap.add_argument("--with-mini-workloads", action="store_true",
                     help="after the timed region run the two post-transcipher mini-workloads (max, inner product mod 2^16) on the "
                          "result LWEs where they lie in HBM (tx_max_u16_io / tx_inner_product_u16_io, device in, device out), "
@@ -235,8 +235,6 @@ def main(argv=None):
     if args.dry_run:
         sys.exit(dry_run(args, rank, world))
 
-    if args.no_ctr_share:
-        os.environ["TX_CTR_SHARE"] = "0"             # read once by tx_create
     import numpy as np
     import torch
     import __graft_entry__
@@ -282,6 +280,8 @@ def main(argv=None):
     luts = keys.round_luts(aes_key, seed=args.seed + 1) if args.mode == "ecb" else keys.ctr_luts(aes_key, seed=args.seed + 1)
     t_keygen = time.time() - t0
     eng = txhip.Engine(p, device=dev_index)
+    if args.no_ctr_share:
+        eng.set_ctr_column_sharing(False)
     t0 = time.time()
     eng.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
     (eng.load_round_luts if args.mode == "ecb" else eng.load_ctr_luts)(luts)
@@ -345,9 +345,8 @@ def main(argv=None):
     # reference's own ECB inverse-cipher schedule (server_encrypted_aes_decryption.rs:130-180) -- one warm-up + two timed steps each
     value_unshared = value_ecb = None
     if world == 1 and args.mode == "ctr" and not args.no_ctr_share and not args.no_equal_work_legs:
-        os.environ["TX_CTR_SHARE"] = "0"
         eng2 = txhip.Engine(p, device=dev_index)
-        del os.environ["TX_CTR_SHARE"]
+        eng2.set_ctr_column_sharing(False)
         eng2.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
         eng2.load_ctr_luts(luts)
         out2 = torch.empty((n_blocks * 128, words), dtype=torch.int64, device=dev)
@@ -471,7 +470,7 @@ def main(argv=None):
                                             "the same counter bytes hold the same ciphertexts in every block; each distinct column is "
                                             "bootstrapped once (64 consecutive counters: 268 of 1024 bytes in that round, the other 8 "
                                             "rounds in full); outputs identical to evaluating every column (value_without_sharing: "
-                                            "timed after the timed region on a second context with TX_CTR_SHARE=0, outputs compared on "
+                                            "timed after the timed region on a second context with column sharing switched off, outputs compared on "
                                             "the device; value_ecb_schedule: the reference's own inverse-cipher schedule, every column "
                                             "in every round)"}),
             "mini_workloads": mini,

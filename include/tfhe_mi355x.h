@@ -7,8 +7,16 @@
  * boundary the reference's stage executables would bind if their hot path were offloaded; each
  * entry point names the reference interface it replaces.  Plain pointers and sizes only, no C++
  * or torch types; return value 0 = success, negative = error (tx_last_error() has the text);
- * no exception crosses the boundary.  One context per GPU; calls on one context must be
- * serialised by the caller (the reference is single-threaded, submission/cbs_lib/Cargo.toml:31-34).
+ * no exception crosses the boundary.
+ *
+ * Threads: a context belongs to one GPU and calls on ONE context must be serialised by the caller
+ * (the reference is single-threaded, submission/cbs_lib/Cargo.toml:31-34).  DISTINCT contexts --
+ * on distinct GPUs, or several on one GPU -- may be driven concurrently from distinct threads:
+ * the library keeps no mutable state outside a context except tx_last_error()'s text, which is
+ * per thread (a thread reads the text of ITS last failed call), and the per-device kernel
+ * attributes tx_create sets under a lock.  Every entry point selects its context's device for
+ * the calling thread (hipSetDevice is per-thread state).  This is how the stage executables
+ * shard an instance across the GPUs of a node: one context and one host thread per device.
  *
  * All ciphertext and key material at the boundary is the reference's standard domain:
  * unsigned 64-bit torus words (q = 2^64), layouts given below.  Fourier-domain forms are private.
@@ -46,9 +54,9 @@ const char *tx_last_error(void);
 
 /* Replaces the key-conversion prologue of `main` (server_encrypted_aes_decryption.rs:640-687):
  * creates a context on HIP device `device`. */
-/* Experiment knobs (environment, read and validated ONCE here; an ill-formed or out-of-range value makes tx_create
- * fail): TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_LUT_VARIANT, TX_BR5_WGS, TX_TRSS_WGS_PER_CU, TX_CTR_SHARE.  Unset = the
- * product path. */
+/* The product library reads NO environment variables.  The experiment build (libtfhe_mi355x_exp.so, -DTXD_EXPERIMENTS: the
+ * superseded kernels kept for A/B tests) reads and validates TX_BR_VARIANT, TX_TRACE_VARIANT, TX_SS_VARIANT, TX_LUT_VARIANT,
+ * TX_BR5_WGS, TX_TRSS_WGS_PER_CU, TX_CTR_SHARE once here; an ill-formed or out-of-range value makes its tx_create fail. */
 tx_ctx *tx_create(const tx_params *p, int device);
 void    tx_destroy(tx_ctx *c);
 
@@ -81,11 +89,33 @@ int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words);
  * n_blocks independent 16-byte AES blocks.  iv == NULL: the reference's ECB inverse-cipher
  * schedule; iv != NULL: CTR mode on counter blocks iv + i (the second round of a CTR batch bootstraps every DISTINCT
  * state column once: the counters of a batch agree in all but their last bytes, so most columns of that round hold the
- * same ciphertexts in every block; same results as evaluating each, TX_CTR_SHARE=0 does).  out_lwe: n_blocks*128 LWE
+ * same ciphertexts in every block; same results as evaluating each, tx_set_ctr_column_sharing(c, 0) does).  out_lwe: n_blocks*128 LWE
  * ciphertexts of kN+1 words, bit order MSB first inside each byte (:182-189).
  * out_is_device != 0: out_lwe is a device pointer on the context's GPU (result stays in HBM). */
 int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
                    uint64_t *out_lwe, int out_is_device);
+
+/* The same call with progress: instances larger than tx_chunk_blocks() blocks are processed chunk by chunk, and with a host
+ * `out_lwe` the LWEs of chunk k travel to the caller's memory on a copy stream while chunk k + 1 computes.  on_chunk (may be
+ * NULL) is called on the calling thread once the LWEs of blocks [first_block, first_block + n_blocks) have ARRIVED in out_lwe --
+ * for every chunk but the last while the GPU is already computing the next one, so that what the caller does with them (the
+ * reference's stage writes them to io/<size>/ciphertext_aes_download, server_encrypted_aes_decryption.rs:699-705) overlaps the
+ * computation.  The callback must not call into the same context.  Pinned memory (tx_host_alloc) makes the copies DMAs. */
+typedef void (*tx_chunk_fn)(void *user, size_t first_block, size_t n_blocks);
+int tx_transcipher_chunks(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv,
+                          uint64_t *out_lwe, int out_is_device, tx_chunk_fn on_chunk, void *user);
+size_t tx_chunk_blocks(void);
+
+/* CTR schedule: evaluate every state column of the second round (enabled = 0) instead of each distinct one once (default 1).
+ * Same ciphertexts either way; the switch exists for equal-work measurements (bench.py's value_without_sharing). */
+int tx_set_ctr_column_sharing(tx_ctx *c, int enabled);
+
+/* Page-locked host memory, usable with every context of the process (hipHostMalloc, portable): result buffers allocated here
+ * are written by DMA at link speed instead of through the runtime's staging copies.  No context needed; NULL on failure. */
+void *tx_host_alloc(size_t bytes);
+int   tx_host_free(void *p);
+/* number of HIP devices visible to the process (what the stage executables shard across by default); negative on error */
+int   tx_device_count(void);
 
 /* Device memory on the context's GPU for the `*_is_device` arguments, for a host that has no HIP binding of its own (the
  * reference's Rust stages): what tx_transcipher(.., out_is_device = 1) writes and tx_max_u16_io / tx_inner_product_u16_io
@@ -166,15 +196,20 @@ typedef struct {
     /* units (bit ciphertexts) all blind-rotation launches of the call processed together: the work actually done, e.g.
      * 8 x 8192 + 2144 for the medium instance under the CTR schedule with its shared second round (round 4) */
     uint64_t units_blind_rotate;
+    /* != 0: a HIP event call failed while the call was being timed; every ms_* field is 0, the call's RESULTS are complete
+     * and the call returned 0 (tx_last_error() names the event call).  The n_* / units_* fields of the blind rotation are
+     * taken from the launches and stay valid. */
+    uint32_t timing_failed;
+    uint32_t reserved_;
 } tx_timing;
 /* tx_timing is APPEND-ONLY: fields are only ever added at the end (round 3: n_br_main, ms_br_main, units_br_main; round 4:
- * units_blind_rotate).  tx_get_timing writes tx_timing_size() bytes: a binding compiled against an older header must
+ * units_blind_rotate; round 5: timing_failed).  tx_get_timing writes tx_timing_size() bytes: a binding compiled against an older header must
  * either be rebuilt or check tx_timing_size() against its own sizeof before it calls tx_get_timing. */
 size_t tx_timing_size(void);
 int tx_get_timing(tx_ctx *c, tx_timing *t);
 /* name of the blind-rotation kernel that processed most units of the last call ("k_blind_rotate5", "k_blind_rotate6",
- * "k_blind_rotate", ...; "" before the first call).  The dispatch is by launch size (and the TX_BR_VARIANT experiment
- * knob, read once by tx_create): the measurement reports what ran, not what a copy of the rule predicts. */
+ * ...; "" until a call of this context has run a blind rotation, then the one of the LAST call that ran any).  The dispatch is
+ * by launch size (in the experiment build also by TX_BR_VARIANT): the measurement reports what ran, not what a copy of the rule predicts. */
 const char *tx_last_blind_rotate_kernel(const tx_ctx *c);
 /* Host logic of that dispatch, exposed for tests and tooling (no context, no GPU): the launches a blind rotation of `count`
  * units is split into on a chip of num_cus CUs -- kernel number (5 = k_blind_rotate5, 6 = k_blind_rotate6, 7 = k_blind_rotate7, 0 = k_blind_rotate)

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -34,6 +35,11 @@ struct tx_ctx {
     tx_params p;
     int device;
     hipStream_t stream;
+    // host-output pipeline of tx_transcipher (round 5): result buffers res / res2 alternate by chunk; chunk k's LWEs go to the
+    // caller's memory on copy_stream while chunk k + 1 computes on `stream`
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    uint64_t *res2 = nullptr;
     // resident evaluation keys (Fourier, private layout)
     cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
     size_t auto_split_stride = 0;
@@ -147,8 +153,9 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     // every failure below releases what was created so far (stream, tables): tx_destroy tolerates a partial context
     if (hipStreamCreate(&c->stream) != hipSuccess) { c->stream = nullptr; fail("tx_create: hipStreamCreate failed"); tx_destroy(c); return nullptr; }
     if (upload_tables(c) != 0) { tx_destroy(c); return nullptr; }
-    // experiment knobs, parsed once and validated here (behind the stream and the tables, so that a bad value also
-    // exercises the release of a half-built context)
+#ifdef TXD_EXPERIMENTS
+    // experiment knobs (the -DTXD_EXPERIMENTS build only: libtfhe_mi355x_exp.so), parsed once and validated here (behind the
+    // stream and the tables, so that a bad value also exercises the release of a half-built context)
     if (env_knob("TX_BR_VARIANT", 0, 7, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
         env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_LUT_VARIANT", 0, 4, c->lut_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
         env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu) || env_knob("TX_CTR_SHARE", 0, 1, c->ctr_share)) { tx_destroy(c); return nullptr; }
@@ -163,42 +170,34 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
             tx_destroy(c); return nullptr;
         }
     }
-    // the trace kernels park two polynomials per wave in LDS: more than the 64 KiB default
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TRACE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TRACE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the trace kernels"); tx_destroy(c); return nullptr;
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
-#ifdef TXD_WITH_BR3
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR3) != hipSuccess ||
 #endif
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate5), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR5) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate6), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR6) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate7), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR7) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_BR3) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the two-wave blind rotation"); tx_destroy(c); return nullptr;
-    }
+    // function attributes are per device and process-wide: contexts created from several threads at once set them in turn
+    static std::mutex attr_mutex;
+    std::lock_guard<std::mutex> attr_lock(attr_mutex);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail("tx_create: hipGetDeviceProperties failed"); tx_destroy(c); return nullptr; }
     c->num_cus = prop.multiProcessorCount;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_trace4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TR4) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TR4) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_scheme_switch4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TR4) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lut_eval4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES_TR4) != hipSuccess) {
-        fail("tx_create: cannot reserve LDS for the generated trace / scheme-switching kernels"); tx_destroy(c); return nullptr;
-    }
+    // every kernel that keeps ciphertext state in LDS needs more than the 64 KiB default
+    auto lds_attr = [](const void *k, size_t bytes) {
+        return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    };
+    bool ok = lds_attr(reinterpret_cast<const void *>(k_blind_rotate5), LDS_BYTES_BR5) &&
+              lds_attr(reinterpret_cast<const void *>(k_blind_rotate6), LDS_BYTES_BR6) &&
+              lds_attr(reinterpret_cast<const void *>(k_blind_rotate7), LDS_BYTES_BR7) &&
+              lds_attr(reinterpret_cast<const void *>(k_extract_trace4), LDS_BYTES_TR4) &&
+              lds_attr(reinterpret_cast<const void *>(k_scheme_switch4), LDS_BYTES_TR4) &&
+              lds_attr(reinterpret_cast<const void *>(k_trace_scheme_switch4), LDS_BYTES_TR4);
+#ifdef TXD_EXPERIMENTS
+    ok = ok && lds_attr(reinterpret_cast<const void *>(k_extract_trace), LDS_BYTES_TRACE) &&
+         lds_attr(reinterpret_cast<const void *>(k_trace), LDS_BYTES_TRACE) &&
+         lds_attr(reinterpret_cast<const void *>(k_blind_rotate), LDS_BYTES_BR) &&
+         lds_attr(reinterpret_cast<const void *>(k_blind_rotate4), LDS_BYTES_BR3) &&
+         lds_attr(reinterpret_cast<const void *>(k_lut_eval4), LDS_BYTES_TR4);
+#ifdef TXD_WITH_BR3
+    ok = ok && lds_attr(reinterpret_cast<const void *>(k_blind_rotate3), LDS_BYTES_BR3);
+#endif
+#endif
+    if (!ok) { fail("tx_create: cannot reserve LDS for the blind-rotation / trace kernels"); tx_destroy(c); return nullptr; }
     return c;
 }
 
@@ -207,8 +206,8 @@ static void free_ws(tx_ctx *c)
     hipFree(c->st); hipFree(c->sm); hipFree(c->small); hipFree(c->acc); hipFree(c->glev); hipFree(c->res);
     hipFree(c->ggsw_f); hipFree(c->d_bytes); hipFree(c->d_ct);
     c->st = c->sm = c->small = c->acc = c->glev = c->res = nullptr; c->ggsw_f = nullptr; c->d_bytes = c->d_ct = nullptr;
-    hipFree(c->share_tmp); hipFree(c->d_idx); hipFree(c->d_pos);
-    c->share_tmp = nullptr; c->d_idx = nullptr; c->d_pos = nullptr; c->share_tmp_bits = 0; c->idx_cap = 0;
+    hipFree(c->share_tmp); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->res2);
+    c->share_tmp = nullptr; c->d_idx = nullptr; c->d_pos = nullptr; c->res2 = nullptr; c->share_tmp_bits = 0; c->idx_cap = 0;
     c->ws_blocks = 0; c->glev_bits = 0;
 }
 
@@ -217,6 +216,8 @@ extern "C" void tx_destroy(tx_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 2; i++) { if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]); if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]); }
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
     hipFree(c->tw); hipFree(c->tw256); hipFree(c->fair_tab); hipFree(c->luts); hipFree(c->ctr_luts);
@@ -237,7 +238,8 @@ static inline int grid_for(size_t units) { return (int)((units + WAVES - 1) / WA
 
 // ---- timing helpers: HIP events on the launch stream ----
 // A failed event call never stops a launch sequence half way (the kernels between ev_begin and ev_end still run): it is
-// remembered in c->ev_error, no further events are recorded for the call, and timing_collect fails the call with it.
+// remembered in c->ev_error, no further events are recorded for the call, and timing_collect reports the call's timing as
+// failed (tx_timing.timing_failed, all times zero) -- the call itself, whose results are complete, still returns 0.
 static void ev_begin(tx_ctx *c, int fam, const char *kernel = "", size_t units = 0)
 {
     if (!c->time_enabled || c->ev_error) return;
@@ -261,11 +263,22 @@ static void ev_end(tx_ctx *c)
 static void timing_reset(tx_ctx *c)
 {
     c->evs.clear(); c->ev_used = 0; memset(&c->timing, 0, sizeof c->timing);
-    c->br_use.clear(); c->last_br_kernel = ""; c->ev_error = nullptr;
+    c->br_use.clear(); c->ev_error = nullptr;       // (last_br_kernel keeps naming the last blind rotation that ran)
 }
 static int timing_collect(tx_ctx *c)
 {
-    if (c->ev_error) return fail(std::string(c->ev_error) + " failed while timing the call (results were computed; no timing reported)");
+    // what ran is taken from the launches themselves (launch_br), so it is right without events too
+    tx_timing &t = c->timing;
+    t.units_br_main = 0; t.n_br_main = 0; t.units_blind_rotate = 0;
+    for (auto &u : c->br_use) {
+        t.units_blind_rotate += u.units;
+        if (u.units > t.units_br_main) { t.units_br_main = u.units; t.n_br_main = u.launches; c->last_br_kernel = u.kernel; }
+    }
+    if (c->ev_error) {       // the measurement failed, not the path: the results are computed and copied
+        t.timing_failed = 1;
+        g_err = std::string(c->ev_error) + " failed while timing the call (results are complete; tx_timing.timing_failed is set)";
+        return 0;
+    }
     if (c->evs.size() != c->ev_used) c->evs.resize(c->ev_used);
     double ms[F_COUNT] = {0}; uint32_t cnt[F_COUNT] = {0};
     // the blind rotation by kernel: a call may use more than one (launch-size dispatch, split tails)
@@ -273,7 +286,11 @@ static int timing_collect(tx_ctx *c)
     std::vector<G> br;
     for (auto &e : c->evs) {
         float t = 0;
-        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return fail("hipEventElapsedTime failed while timing the call");
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) {
+            c->timing.timing_failed = 1;
+            g_err = "hipEventElapsedTime failed while timing the call (results are complete; tx_timing.timing_failed is set)";
+            return 0;
+        }
         ms[e.fam] += t; cnt[e.fam]++;
         if (e.fam == F_BR) {
             size_t g = 0;
@@ -282,18 +299,12 @@ static int timing_collect(tx_ctx *c)
             br[g].ms += t; br[g].n++; br[g].units += e.units;
         }
     }
-    tx_timing &t = c->timing;
     t.ms_keyswitch = ms[F_KS]; t.ms_blind_rotate = ms[F_BR]; t.ms_trace = ms[F_TRACE];
     t.ms_scheme_switch = ms[F_SS]; t.ms_lut_eval = ms[F_LUT]; t.ms_linear = ms[F_LIN];
     t.n_keyswitch = cnt[F_KS]; t.n_blind_rotate = cnt[F_BR]; t.n_trace = cnt[F_TRACE];
     t.n_scheme_switch = cnt[F_SS]; t.n_lut_eval = cnt[F_LUT]; t.n_linear = cnt[F_LIN];
     t.ms_total = 0; for (int i = 0; i < F_COUNT; i++) t.ms_total += ms[i];
-    // what ran is taken from the launches themselves (launch_br), so it is also right in a build without events
-    t.ms_br_main = 0; t.n_br_main = 0; t.units_br_main = 0; t.units_blind_rotate = 0;
-    for (auto &u : c->br_use) {
-        t.units_blind_rotate += u.units;
-        if (u.units > t.units_br_main) { t.units_br_main = u.units; t.n_br_main = u.launches; c->last_br_kernel = u.kernel; }
-    }
+    t.ms_br_main = 0;
     for (auto &g : br)
         if (t.units_br_main && strcmp(g.k, c->last_br_kernel) == 0) t.ms_br_main = g.ms;
     return 0;
@@ -366,6 +377,28 @@ extern "C" int tx_device_download(tx_ctx *c, void *dst_host, const void *src_dev
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ---- pinned host memory (no context: usable by every device, from any thread) ----
+extern "C" void *tx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocPortable) != hipSuccess) {
+        fail("tx_host_alloc: hipHostMalloc of " + std::to_string(bytes) + " bytes failed"); return nullptr;
+    }
+    return p;
+}
+extern "C" int tx_host_free(void *p)
+{
+    if (!p) return 0;
+    HIP_OK(hipHostFree(p));
+    return 0;
+}
+extern "C" int tx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return fail("tx_device_count: hipGetDeviceCount failed (no HIP device, and no CPU fallback)");
+    return n;
 }
 
 // device buffer released on every exit path
@@ -507,8 +540,12 @@ static void br_used(tx_ctx *c, const char *kernel, size_t units)
 static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, uint64_t *acc)
 {
     const int n = (int)c->p.n;
+#ifdef TXD_EXPERIMENTS
     br_used(c, variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" : variant == 4 ? "k_blind_rotate4" :
                variant == 3 ? "k_blind_rotate3" : "k_blind_rotate", count);
+#else
+    br_used(c, variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : "k_blind_rotate5", count);
+#endif
     if (variant == 7) {
         ev_begin(c, F_BR, "k_blind_rotate7", count);
         hipLaunchKernelGGL(k_blind_rotate7, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
@@ -528,6 +565,7 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
         if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
         ev_begin(c, F_BR, "k_blind_rotate5", count);
         hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+#ifdef TXD_EXPERIMENTS
     } else if (variant == 4) {
         ev_begin(c, F_BR, "k_blind_rotate4", count);
         hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
@@ -540,6 +578,9 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
         ev_begin(c, F_BR, "k_blind_rotate", count);
         hipLaunchKernelGGL(k_blind_rotate, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
     }
+#else
+    }
+#endif
     ev_end(c);
 }
 static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
@@ -574,23 +615,27 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
 static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint64_t *glev)
 {
     ev_begin(c, F_TRACE);
-    if (c->trace_variant == 4)
-        hipLaunchKernelGGL(k_extract_trace4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, acc, glev,
+#ifdef TXD_EXPERIMENTS
+    if (c->trace_variant != 4)
+        hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TRACE, c->stream, acc, glev,
                            (int)count, c->auto_f, c->auto_split_stride, c->tw);
     else
-    hipLaunchKernelGGL(k_extract_trace, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TRACE, c->stream, acc, glev,
-                       (int)count, c->auto_f, c->auto_split_stride, c->tw);
+#endif
+        hipLaunchKernelGGL(k_extract_trace4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, acc, glev,
+                           (int)count, c->auto_f, c->auto_split_stride, c->tw);
     ev_end(c);
 }
 static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
 {
     ev_begin(c, F_SS);
-    if (c->ss_variant == 4)
-        hipLaunchKernelGGL(k_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, glev, ggsw_f,
+#ifdef TXD_EXPERIMENTS
+    if (c->ss_variant != 4)
+        hipLaunchKernelGGL(k_scheme_switch, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, glev, ggsw_f,
                            (int)(count * CBS_L), c->ss_f, c->tw);
     else
-    hipLaunchKernelGGL(k_scheme_switch, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES, c->stream, glev, ggsw_f,
-                       (int)(count * CBS_L), c->ss_f, c->tw);
+#endif
+        hipLaunchKernelGGL(k_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, glev, ggsw_f,
+                           (int)(count * CBS_L), c->ss_f, c->tw);
     ev_end(c);
 }
 static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t *lut_set, size_t lut_stride, int nlut,
@@ -598,10 +643,12 @@ static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t
 {
     ev_begin(c, F_LUT);
     const dim3 grid((grid_for(nbytes * nlut * 2) + 7) / 8 * 8);      // a multiple of 8: the kernels deal the units out XCD by XCD
+#ifdef TXD_EXPERIMENTS
     if (c->lut_variant == 4)
         hipLaunchKernelGGL(k_lut_eval4, grid, dim3(256), LDS_BYTES_TR4, c->stream, ggsw_f, lut_set,
                            lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
     else
+#endif
         hipLaunchKernelGGL(k_lut_eval, grid, dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
                            lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
     ev_end(c);
@@ -672,8 +719,10 @@ extern "C" int tx_ctr_shared_columns(const uint8_t *iv, size_t first_block, size
 }
 
 // ---- a1: round schedules ----
+// `spare`: a buffer of nb x 128 big LWEs that is free until the chunk's last kernel (the result buffer the chunk will be
+// finalised into qualifies: nothing reads it before); the CTR schedule parks the compact state of its shared round there
 static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint8_t *iv, size_t blk0, int rounds_done,
-                             uint64_t *d_out, bool reference_order)
+                             uint64_t *d_out, bool reference_order, uint64_t *spare)
 {
     const size_t bits = nb * 128, blkw = (size_t)128 * BIG;
     const size_t mult_sz = (size_t)16 * 2 * GL;
@@ -764,7 +813,7 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
             hipLaunchKernelGGL(k_linear, dim3(ew_grid(bits * BIG)), dim3(256), 0, c->stream, c->sm, c->st, (int)nb, 0);
             ev_end(c);
             if (s == 1 && share) {
-                uint64_t *cst = c->res;                         // compact state: the distinct columns (c->res is free during the rounds)
+                uint64_t *cst = spare;                          // compact state: the distinct columns
                 ev_begin(c, F_LIN);
                 hipLaunchKernelGGL(k_gather_cols, dim3(ew_grid(ucols * 32 * BIG)), dim3(256), 0, c->stream, c->st, c->d_idx, cst, (int)ucols);
                 ev_end(c);
@@ -789,8 +838,23 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
 
 static const size_t CHUNK_BLOCKS = 128;
 
+// Host output (round 5): the chunks' results alternate between two device buffers; chunk k's LWEs travel to the caller's
+// memory on copy_stream while chunk k + 1 computes, and `cb` (may be null) is called on the calling thread for every chunk
+// whose LWEs have ARRIVED in `out` -- for chunk k - 1 right after chunk k has been enqueued, so that the caller's work on
+// it (writing a file) overlaps the GPU's.  A pinned `out` (tx_host_alloc) makes the copy a DMA at link speed.
+static int pipeline_init(tx_ctx *c)
+{
+    if (c->copy_stream) return 0;
+    HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_OK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
 static int transcipher_impl(tx_ctx *c, const uint8_t *ct, size_t n_blocks, const uint8_t *iv, int rounds_done,
-                            uint64_t *out, int out_is_device, bool reference_order)
+                            uint64_t *out, int out_is_device, bool reference_order, tx_chunk_fn cb = nullptr, void *user = nullptr)
 {
     if (!c || !ct || !out) return fail("tx_transcipher: null argument");
     if (!c->have_keys) return fail("tx_transcipher: evaluation keys not loaded");
@@ -799,20 +863,54 @@ static int transcipher_impl(tx_ctx *c, const uint8_t *ct, size_t n_blocks, const
     timing_reset(c);
     const size_t chunk = n_blocks < CHUNK_BLOCKS ? n_blocks : CHUNK_BLOCKS;
     if (ensure_ws(c, chunk)) return -1;
-    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
-        size_t nb = (n_blocks - b0 < chunk) ? n_blocks - b0 : chunk;
-        uint64_t *dst = out_is_device ? out + b0 * 128 * BIG : c->res;
-        if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, dst, reference_order)) return -1;
-        if (!out_is_device)
-            HIP_OK(hipMemcpyAsync(out + b0 * 128 * BIG, c->res, nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_is_device) {
+        for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+            const size_t nb = std::min(chunk, n_blocks - b0);
+            if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, out + b0 * 128 * BIG, reference_order, c->res)) return -1;
+            if (cb) { HIP_OK(hipStreamSynchronize(c->stream)); cb(user, b0, nb); }
+        }
         HIP_OK(hipStreamSynchronize(c->stream));
+        return timing_collect(c);
     }
+    if (pipeline_init(c)) return -1;
+    if (n_blocks > chunk && !c->res2) HIP_OK(hipMalloc(&c->res2, c->ws_blocks * 128 * BIG * 8));
+    uint64_t *buf[2] = { c->res, c->res2 };
+    size_t prev_b0 = 0, prev_nb = 0; int prev = -1;
+    int k = 0;
+    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk, k ^= 1) {
+        const size_t nb = std::min(chunk, n_blocks - b0);
+        // buf[k] was the source of the copy two chunks ago: the compute stream may not write it before that copy is done
+        if (b0 >= 2 * chunk) HIP_OK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+        if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, buf[k], reference_order, buf[k])) return -1;
+        HIP_OK(hipEventRecord(c->ev_done[k], c->stream));
+        HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_done[k], 0));
+        HIP_OK(hipMemcpyAsync(out + b0 * 128 * BIG, buf[k], nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_OK(hipEventRecord(c->ev_copied[k], c->copy_stream));
+        if (prev >= 0 && cb) { HIP_OK(hipEventSynchronize(c->ev_copied[prev])); cb(user, prev_b0, prev_nb); }
+        prev = k; prev_b0 = b0; prev_nb = nb;
+    }
+    HIP_OK(hipStreamSynchronize(c->copy_stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (cb) cb(user, prev_b0, prev_nb);
     return timing_collect(c);
 }
 
 extern "C" int tx_transcipher(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv, uint64_t *out_lwe,
                               int out_is_device)
 { return transcipher_impl(c, ct_blocks, n_blocks, iv, 9, out_lwe, out_is_device, false); }
+
+extern "C" int tx_transcipher_chunks(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, const uint8_t *iv, uint64_t *out_lwe,
+                                     int out_is_device, tx_chunk_fn on_chunk, void *user)
+{ return transcipher_impl(c, ct_blocks, n_blocks, iv, 9, out_lwe, out_is_device, false, on_chunk, user); }
+
+extern "C" size_t tx_chunk_blocks(void) { return CHUNK_BLOCKS; }
+
+extern "C" int tx_set_ctr_column_sharing(tx_ctx *c, int enabled)
+{
+    if (!c) return fail("tx_set_ctr_column_sharing: null context");
+    c->ctr_share = enabled ? 1 : 0;
+    return 0;
+}
 
 extern "C" int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, int rounds_done, uint64_t *out_state)
 {

@@ -279,6 +279,7 @@ void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // registers.  The HIP part loads the twiddles, builds the rotated test vector in the wave's LDS slice and hands
 // five scalars to the loop; the loop stores the accumulator itself.  Same LDS image as k_blind_rotate3.
 // ------------------------------------------------------------------------------------------
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256, 2)
 void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
 {
@@ -332,6 +333,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     );
 #endif
 }
+#endif  // TXD_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // k_blind_rotate5: the generated loop with FAIR arbitration.  With two independent workgroups per CU the older wave of
@@ -756,6 +758,7 @@ void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx 
 // selector in flight; parking the digit transforms in accumulation registers to widen the ring would bring the key pass to
 // ~20 k and the step to ~89 k against hipcc's ~95 k -- 0.3 % of a round -- and was not built (profiles/r4t_*).
 // ------------------------------------------------------------------------------------------
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_lut_eval4(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride, size_t byte_stride, uint64_t *out, int nbytes, int nlut,
                  const cplx *tw_g, const uint8_t *pos)
@@ -815,6 +818,7 @@ void k_lut_eval4(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride, si
         if (lane2 == 0) o[2 * N] = gl[2 * N + nth];
     }
 }
+#endif  // TXD_EXPERIMENTS
 
 // a6 + a7 + a8 + a9 in one kernel: the traced GLev element stays in the wave's LDS slice and goes straight into the
 // scheme switch -- no GLev round trip through HBM (24 KiB out and in per unit) and one workgroup start (twiddle image,

@@ -417,6 +417,7 @@ __device__ __forceinline__ double pbs_digit(uint64_t x, uint32_t thr)
     return (double)d;
 }
 
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_blind_rotate(const uint64_t *lwe, uint64_t *acc_out, int count, int n,
                                                       const cplx *bsk_f, const cplx *tw_g)
 {
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = accl[q * N + lane + 64 * m];
 }
+#endif  // TXD_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // a6 + a7: per (ciphertext, level): extract level from the rotated accumulator, divide by N
@@ -738,6 +740,7 @@ __device__ __forceinline__ KeyRing ring_setup(unsigned char *lds, size_t wave_by
     return k;
 }
 
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_extract_trace(const uint64_t *acc, uint64_t *glev, int count,
                                                        const cplx *auto_f, size_t split_stride, const cplx *tw_g)
 {
@@ -774,8 +777,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int m = 0; m < 16; m++) o[q * N + lane + 64 * m] = gl[q * N + lane + 64 * m];
 }
+#endif  // TXD_EXPERIMENTS
 
 // trace_assign alone on `count` GLWEs in place (unit parity for a7)
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_trace(uint64_t *glwe, int count, const cplx *auto_f, size_t split_stride,
                                                const cplx *tw_g)
 {
@@ -798,6 +803,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int m = 0; m < 16; m++) p[q * N + w.lane + 64 * m] = gl[q * N + w.lane + 64 * m];
 }
+#endif  // TXD_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // a8 + a9: scheme switching GLev -> GGSW, emitted directly in the Fourier domain
@@ -832,6 +838,7 @@ struct SsKeyFn {
 // The six digit polynomials of the GLev element (3 polynomials x 2 levels) are transformed ONCE and serve both
 // mask rows; the scheme-switching key is the same for every unit, so each pass takes its 18 key polynomials from
 // the workgroup's shared ring (see the trace kernel).  Same products in the same order as extprod_row.
+#ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_scheme_switch(const uint64_t *glev, cplx *ggsw_f, int units,
                                                        const cplx *ss_f, const cplx *tw_g)
 {
@@ -901,6 +908,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         store_fourier_scaled3(in, o + (size_t)2 * KP * H, w);
     }
 }
+#endif  // TXD_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // a10: CMux tree over the 8 selector GGSWs of a byte (SRV_AES:550-588).

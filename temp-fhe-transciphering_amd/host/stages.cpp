@@ -4,19 +4,37 @@
 // The server stages are thin wrappers: read files -> C ABI (libtfhe_mi355x.so) -> write files.
 // File format between this repo's own stages (private, like the reference's bincode files):
 // 16-byte header {magic "TXU64\0\0\0", word count} followed by little-endian u64 words.
+//
+// Round 5: the two server stages shard the instance across the GPUs of the node IN-PROCESS -- one
+// tx_ctx and one host thread per device (TX_DEVICES, default: every visible GPU), the evaluation keys
+// read once from io/<size>/public_keys/*.bin and uploaded to each device, contiguous slabs of AES
+// blocks written straight into the shared result (disjoint ranges), so that the 8-GPU split of
+// SURVEY.md 8(e) is what a harness user gets from `server_encrypted_aes_decryption <size>` itself
+// (harness/run_submission.py:91-99).  Result LWEs land in page-locked memory by DMA while the next
+// chunk computes and are written to the result file from there, also while the next chunk computes.
 #include "txclient.h"
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
+
+const uint64_t MAGIC = 0x0000003436555854ull;   // "TXU64"
 
 const char *size_name(int s)
 {   // submission/src/help_fun.rs:3-10
@@ -32,29 +50,50 @@ void mkdirs(const std::string &p)
     for (size_t i = 0; i <= p.size(); i++)
         if (i == p.size() || p[i] == '/') { cur = p.substr(0, i); if (!cur.empty()) mkdir(cur.c_str(), 0755); }
 }
-void write_words(const std::string &path, const std::vector<uint64_t> &v)
+void write_words(const std::string &path, const uint64_t *v, size_t n)
 {
     mkdirs(path.substr(0, path.find_last_of('/')));
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) throw std::runtime_error("cannot write " + path);
-    uint64_t hdr[2] = { 0x0000003436555854ull /* "TXU64" */, v.size() };
-    if (fwrite(hdr, 8, 2, f) != 2 || fwrite(v.data(), 8, v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short write " + path); }
+    uint64_t hdr[2] = { MAGIC, n };
+    if (fwrite(hdr, 8, 2, f) != 2 || fwrite(v, 8, n, f) != n) { fclose(f); throw std::runtime_error("short write " + path); }
     fclose(f);
 }
+void write_words(const std::string &path, const std::vector<uint64_t> &v) { write_words(path, v.data(), v.size()); }
+
+// a TXU64 file mapped read-only: the words are used where the page cache holds them (the 56.6 MB bootstrapping key and the
+// result LWEs of the previous stage are uploaded straight from the mapping, no copy into a vector first)
+struct Mapped {
+    const uint64_t *words = nullptr; size_t n = 0;
+    void *base = MAP_FAILED; size_t len = 0;
+    Mapped() = default;
+    Mapped(const Mapped &) = delete;
+    Mapped &operator=(const Mapped &) = delete;
+    ~Mapped() { if (base != MAP_FAILED) munmap(base, len); }
+    const uint64_t *data() const { return words; }
+    size_t size() const { return n; }
+    void open(const std::string &path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot read " + path);
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size < 16) { close(fd); throw std::runtime_error("bad header in " + path); }
+        len = (size_t)sb.st_size;
+        base = mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+        const uint64_t *h = (const uint64_t *)base;
+        if (h[0] != MAGIC) throw std::runtime_error("bad header in " + path);
+        // the header's word count must be what the file holds (a truncated or foreign file is an error before any GPU work)
+        if ((len - 16) % 8 != 0 || (uint64_t)(len - 16) / 8 != h[1])
+            throw std::runtime_error("word count in the header of " + path + " does not match the file size");
+        words = h + 2; n = (size_t)h[1];
+    }
+};
 std::vector<uint64_t> read_words(const std::string &path)
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot read " + path);
-    uint64_t hdr[2];
-    if (fread(hdr, 8, 2, f) != 2 || hdr[0] != 0x0000003436555854ull) { fclose(f); throw std::runtime_error("bad header in " + path); }
-    struct stat sb;                                     // the header's word count must be what the file holds
-    if (fstat(fileno(f), &sb) != 0 || sb.st_size < 16 || (uint64_t)(sb.st_size - 16) / 8 != hdr[1] || (sb.st_size - 16) % 8 != 0) {
-        fclose(f); throw std::runtime_error("word count in the header of " + path + " does not match the file size");
-    }
-    std::vector<uint64_t> v(hdr[1]);
-    if (fread(v.data(), 8, v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short read " + path); }
-    fclose(f);
-    return v;
+    Mapped m; m.open(path);
+    return std::vector<uint64_t>(m.data(), m.data() + m.size());
 }
 std::string read_text(const std::string &path)
 {
@@ -68,8 +107,14 @@ std::string read_text(const std::string &path)
 std::vector<uint8_t> from_hex(const std::string &h)
 {
     if (h.size() % 2) throw std::runtime_error("odd hex length");
+    auto nib = [](char c) -> int {
+        if (c >= '0' && c <= '9') return c - '0';
+        if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+        if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+        throw std::runtime_error("not a hex digit");
+    };
     std::vector<uint8_t> out(h.size() / 2);
-    for (size_t i = 0; i < out.size(); i++) out[i] = (uint8_t)std::stoul(h.substr(2 * i, 2), nullptr, 16);
+    for (size_t i = 0; i < out.size(); i++) out[i] = (uint8_t)(nib(h[2 * i]) * 16 + nib(h[2 * i + 1]));
     return out;
 }
 uint64_t env_seed(const char *name) { const char *s = getenv(name); return s ? strtoull(s, nullptr, 10) : 0; }
@@ -80,6 +125,30 @@ struct Paths {
 };
 
 void check(int rc, const char *what) { if (rc != 0) throw std::runtime_error(std::string(what) + ": " + tx_last_error()); }
+
+// TX_STAGE_TIMING=1: where a server stage's wall time goes, one JSON line on stderr (TX_STAGE_TIMING=<path>: appended there).
+// The harness times whole processes (harness/utils.py:85-109); this says what of that is the GPU's.
+struct Clock {
+    using clk = std::chrono::steady_clock;
+    clk::time_point t0 = clk::now();
+    std::mutex m;
+    std::vector<std::pair<std::string, double>> marks;
+    double now() const { return std::chrono::duration<double>(clk::now() - t0).count(); }
+    void mark(const std::string &name) { const double t = now(); std::lock_guard<std::mutex> g(m); marks.emplace_back(name, t); }
+    void report(const char *stage, int size, size_t devices)
+    {
+        const char *e = getenv("TX_STAGE_TIMING");
+        if (!e || !*e || !strcmp(e, "0")) return;
+        std::ostringstream o;
+        o.setf(std::ios::fixed); o.precision(4);
+        o << "{\"stage\": \"" << stage << "\", \"size\": " << size << ", \"devices\": " << devices << ", \"total_s\": " << now() << ", \"at_s\": {";
+        for (size_t i = 0; i < marks.size(); i++) o << (i ? ", " : "") << "\"" << marks[i].first << "\": " << marks[i].second;
+        o << "}}\n";
+        if (!strcmp(e, "1")) { fputs(o.str().c_str(), stderr); return; }
+        FILE *f = fopen(e, "a");
+        if (f) { fputs(o.str().c_str(), f); fclose(f); }
+    }
+};
 
 // ---------------- client stages ----------------
 int client_key_generation(int size)
@@ -120,7 +189,7 @@ int client_decrypt(int size, const char *in_dir, const char *out_name)
     Paths p(size);
     tx_params prm; tx_params_aes_tight(&prm);
     std::vector<uint64_t> glwe = read_words(p.io + "/secret_keys/glwe_sk.bin");
-    std::vector<uint64_t> ct = read_words(p.io + "/" + in_dir + "/result.bin");
+    Mapped ct; ct.open(p.io + "/" + in_dir + "/result.bin");
     const size_t big = (size_t)prm.k * prm.N + 1, cnt = ct.size() / big;
     std::vector<uint8_t> bits(cnt);
     txc_decrypt_bits(&prm, glwe.data(), ct.data(), cnt, bits.data());
@@ -141,52 +210,243 @@ int client_postprocess(int size, const char *in_name, const char *out_name)
 }
 
 // ---------------- server stages ----------------
-tx_ctx *server_context(const Paths &p, const tx_params &prm)
-{   // SRV_AES:620-687
-    // the key files are read and checked first: a truncated or foreign file is an error before any GPU work
-    std::vector<uint64_t> bsk = read_words(p.io + "/public_keys/bsk.bin"), ksk = read_words(p.io + "/public_keys/ksk.bin"),
-        au = read_words(p.io + "/public_keys/auto_keys.bin"), ss = read_words(p.io + "/public_keys/ss_key.bin");
-    if (bsk.size() != txc_bsk_words(&prm) || ksk.size() != txc_ksk_words(&prm) || au.size() != txc_auto_words(&prm) ||
-        ss.size() != txc_ss_words(&prm)) throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set");
-    int dev = getenv("TX_DEVICE") ? atoi(getenv("TX_DEVICE")) : 0;
+// Which GPUs a server stage uses: TX_DEVICES = comma-separated HIP device indices, one context each (an index may repeat:
+// "0,0" puts two contexts on one card, which is how the one-GPU tests run the sharded path); TX_DEVICE = one index (rounds
+// 1-4); neither: every device the process can see.  Never more contexts than `useful` (units of work to deal out).
+std::vector<int> device_list(size_t useful)
+{
+    std::vector<int> d;
+    if (const char *e = getenv("TX_DEVICES")) {
+        const char *s = e;
+        while (*s) {
+            char *end = nullptr;
+            const long v = strtol(s, &end, 10);
+            if (end == s || v < 0 || v > 1023 || (*end != ',' && *end != 0))
+                throw std::runtime_error(std::string("TX_DEVICES=") + e + " is not a comma-separated list of device indices");
+            d.push_back((int)v);
+            s = *end ? end + 1 : end;
+            if (*end == ',' && !*s) throw std::runtime_error(std::string("TX_DEVICES=") + e + " ends with a comma");
+        }
+        if (d.empty()) throw std::runtime_error("TX_DEVICES is empty");
+    } else if (const char *e1 = getenv("TX_DEVICE")) {
+        d.push_back(atoi(e1));
+    } else {
+        const int n = tx_device_count();
+        if (n <= 0) throw std::runtime_error(std::string("no HIP device (the HIP path is mandatory, there is no CPU fallback): ") + tx_last_error());
+        for (int i = 0; i < n; i++) d.push_back(i);
+    }
+    if (d.size() > useful) d.resize(useful ? useful : 1);
+    return d;
+}
+// contiguous slab [start, start + count) of part r of `world` (the rule of python/txdist.py shard())
+void slab(size_t n, size_t world, size_t r, size_t &start, size_t &count)
+{
+    const size_t per = (n + world - 1) / world;
+    start = std::min(r * per, n);
+    count = std::min(per, n - start);
+}
+void iv_add(const uint8_t iv[16], uint64_t k, uint8_t out[16])
+{   // 128-bit big-endian counter (harness/aes_keygen_and_encrypt.py:52-54)
+    memcpy(out, iv, 16);
+    for (int i = 15; i >= 0 && k; i--) { const uint64_t v = (uint64_t)out[i] + (k & 0xFF); out[i] = (uint8_t)v; k = (k >> 8) + (v >> 8); }
+}
+
+struct EvalKeyFiles {
+    Mapped bsk, ksk, au, ss;
+    void open(const Paths &p, const tx_params &prm)
+    {   // SRV_AES:620-643.  Read and checked first: a truncated or foreign file is an error before any GPU work
+        ksk.open(p.io + "/public_keys/ksk.bin"); au.open(p.io + "/public_keys/auto_keys.bin"); ss.open(p.io + "/public_keys/ss_key.bin");
+        bsk.open(p.io + "/public_keys/bsk.bin");
+        if (bsk.size() != txc_bsk_words(&prm) || ksk.size() != txc_ksk_words(&prm) || au.size() != txc_auto_words(&prm) ||
+            ss.size() != txc_ss_words(&prm)) throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set");
+    }
+};
+tx_ctx *make_context(const tx_params &prm, int dev, const EvalKeyFiles &k)
+{   // SRV_AES:646-687: conversion of the keys to their evaluation form, here on the GPU, once per context
     tx_ctx *c = tx_create(&prm, dev);
-    if (!c) throw std::runtime_error(std::string("tx_create: ") + tx_last_error());
-    check(tx_load_eval_keys(c, bsk.data(), bsk.size(), ksk.data(), ksk.size(), au.data(), au.size(), ss.data(), ss.size()),
-          "tx_load_eval_keys");
+    if (!c) throw std::runtime_error(std::string("tx_create (device ") + std::to_string(dev) + "): " + tx_last_error());
+    if (tx_load_eval_keys(c, k.bsk.data(), k.bsk.size(), k.ksk.data(), k.ksk.size(), k.au.data(), k.au.size(), k.ss.data(), k.ss.size())) {
+        std::string m = std::string("tx_load_eval_keys: ") + tx_last_error();
+        tx_destroy(c);
+        throw std::runtime_error(m);
+    }
     return c;
 }
+// run fn(r) for r < n on n threads; the first exception (with its thread's tx_last_error text already in it) is rethrown
+template <class F> void on_threads(size_t n, F fn)
+{
+    std::vector<std::string> err(n);
+    std::vector<std::thread> th;
+    auto body = [&](size_t r) { try { fn(r); } catch (const std::exception &e) { err[r] = e.what(); if (err[r].empty()) err[r] = "failed"; } };
+    for (size_t r = 1; r < n; r++) th.emplace_back(body, r);
+    body(0);
+    for (auto &t : th) t.join();
+    for (size_t r = 0; r < n; r++) if (!err[r].empty()) throw std::runtime_error(n > 1 ? "[part " + std::to_string(r) + "] " + err[r] : err[r]);
+}
+
+// result file written piecewise: the chunks of all devices go to disjoint ranges (pwrite), each as soon as it has arrived
+struct ResultFile {
+    int fd = -1; std::string path;
+    void create(const std::string &p, size_t words)
+    {
+        path = p;
+        mkdirs(p.substr(0, p.find_last_of('/')));
+        fd = ::open(p.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fd < 0) throw std::runtime_error("cannot write " + p);
+        const uint64_t hdr[2] = { MAGIC, words };
+        if (ftruncate(fd, (off_t)(16 + words * 8)) != 0 || pwrite(fd, hdr, 16, 0) != 16) throw std::runtime_error("short write " + p);
+    }
+    void put_range(const uint64_t *src, size_t word0, size_t words) const
+    {
+        const char *s = (const char *)src; size_t left = words * 8; off_t off = (off_t)(16 + word0 * 8);
+        while (left) {
+            const ssize_t w = pwrite(fd, s, left, off);
+            if (w <= 0) { if (w < 0 && errno == EINTR) continue; throw std::runtime_error("short write " + path); }
+            s += w; left -= (size_t)w; off += w;
+        }
+    }
+    // a chunk goes out on a few threads: page-cache writes are memory copies, and the last chunk of a device is the one write
+    // nothing else hides
+    void put(const uint64_t *src, size_t word0, size_t words) const
+    {
+        const size_t parts = words * 8 >= (32u << 20) ? 4 : 1, per = (words + parts - 1) / parts;
+        on_threads(parts, [&](size_t r) {
+            const size_t a = std::min(r * per, words), b = std::min(a + per, words);
+            if (b > a) put_range(src + a, word0 + a, b - a);
+        });
+    }
+    void finish() { if (fd >= 0 && close(fd) != 0) { fd = -1; throw std::runtime_error("short write " + path); } fd = -1; }
+    ~ResultFile() { if (fd >= 0) close(fd); }
+};
+
 int server_encrypted_aes_decryption(int size)
 {   // SRV_AES:599-707, all blocks of db.hex
+    Clock clk;
     Paths p(size);
     tx_params prm; tx_params_aes_tight(&prm);
     std::vector<uint8_t> ct = from_hex(read_text(p.data + "/db.hex"));
     if (ct.empty() || ct.size() % 16) throw std::runtime_error("db.hex must hold whole 16-byte blocks");
-    tx_ctx *c = server_context(p, prm);
-    std::vector<uint64_t> luts = read_words(p.io + "/ciphertexts_upload/trans_key.bin");
+    const size_t nb = ct.size() / 16, big = (size_t)prm.k * prm.N + 1, blkw = 128 * big;
+    EvalKeyFiles keys; keys.open(p, prm);
+    Mapped luts; luts.open(p.io + "/ciphertexts_upload/trans_key.bin");
     std::vector<uint8_t> iv;
-    if (size == 0) check(tx_load_round_luts(c, luts.data(), luts.size()), "tx_load_round_luts");
-    else { check(tx_load_ctr_luts(c, luts.data(), luts.size()), "tx_load_ctr_luts"); iv = from_hex(read_text(p.data + "/aes_iv.hex")); }
-    const size_t nb = ct.size() / 16, big = (size_t)prm.k * prm.N + 1;
-    std::vector<uint64_t> out(nb * 128 * big);
-    check(tx_transcipher(c, ct.data(), nb, size == 0 ? nullptr : iv.data(), out.data(), 0), "tx_transcipher");
-    tx_destroy(c);
-    write_words(p.io + "/ciphertext_aes_download/result.bin", out);
+    if (size != 0) { iv = from_hex(read_text(p.data + "/aes_iv.hex")); if (iv.size() != 16) throw std::runtime_error("aes_iv.hex must hold 16 bytes"); }
+    clk.mark("files_mapped");
+    const std::vector<int> devs = device_list(nb);
+    const size_t D = devs.size();
+    ResultFile out; out.create(p.io + "/ciphertext_aes_download/result.bin", nb * blkw);
+    struct Part { const ResultFile *out; const uint64_t *host; size_t blk0, blkw; };
+    on_threads(D, [&](size_t r) {
+        size_t b0, cnt; slab(nb, D, r, b0, cnt);
+        if (cnt == 0) return;
+        const std::string tag = D > 1 ? "[" + std::to_string(r) + "]" : "";
+        // page-locked landing area of this slab: allocated on a thread of its own while the context is built and the keys are
+        // transformed (pinning 134 MB costs as much as uploading the keys)
+        uint64_t *host = nullptr; std::string host_err;
+        std::thread pin([&] { host = (uint64_t *)tx_host_alloc(cnt * blkw * 8); if (!host) host_err = tx_last_error(); });
+        tx_ctx *c = nullptr;
+        try {
+            c = make_context(prm, devs[r], keys);
+            clk.mark("keys_resident" + tag);
+            if (size == 0) check(tx_load_round_luts(c, luts.data(), luts.size()), "tx_load_round_luts");
+            else check(tx_load_ctr_luts(c, luts.data(), luts.size()), "tx_load_ctr_luts");
+            clk.mark("luts_resident" + tag);
+        } catch (...) { pin.join(); tx_host_free(host); if (c) tx_destroy(c); throw; }
+        pin.join();
+        if (!host) { tx_destroy(c); throw std::runtime_error("tx_host_alloc: " + host_err); }
+        clk.mark("pinned" + tag);
+        uint8_t iv_r[16];
+        if (size != 0) iv_add(iv.data(), b0, iv_r);
+        Part part{ &out, host, b0, blkw };
+        std::string cb_err;
+        struct Cb { Part *p; std::string *err; Clock *clk; const std::string *tag; } cb{ &part, &cb_err, &clk, &tag };
+        const int rc = tx_transcipher_chunks(c, ct.data() + b0 * 16, cnt, size == 0 ? nullptr : iv_r, host, 0,
+            [](void *u, size_t first, size_t n) {
+                Cb *k = (Cb *)u;
+                try { k->p->out->put(k->p->host + first * k->p->blkw, (k->p->blk0 + first) * k->p->blkw, n * k->p->blkw); }
+                catch (const std::exception &e) { if (k->err->empty()) *k->err = e.what(); }
+                k->clk->mark("chunk_written" + *k->tag + "@" + std::to_string(first));
+            }, &cb);
+        const std::string err = rc ? std::string("tx_transcipher: ") + tx_last_error() : cb_err;
+        clk.mark("transciphered" + tag);
+        tx_destroy(c);
+        tx_host_free(host);
+        if (!err.empty()) throw std::runtime_error(err);
+    });
+    out.finish();
+    clk.mark("done");
+    clk.report("server_encrypted_aes_decryption", size, D);
     return 0;
 }
+
 int server_encrypted_compute(int size, int mini_workload)
 {   // SRV_CMP:99-359 (mini-workload 0: max); mini-workload 1 (inner product, cleartext_impl.py:65-70) has no
     // server implementation in the reference
+    Clock clk;
     Paths p(size);
     tx_params prm; tx_params_aes_tight(&prm);
-    std::vector<uint64_t> in = read_words(p.io + "/ciphertext_aes_download/result.bin");
-    const size_t big = (size_t)prm.k * prm.N + 1, nvals = in.size() / big / 16;
-    if (nvals == 0 || in.size() != nvals * 16 * big) throw std::runtime_error("lwe_ciphertext_list length is not a multiple of 16");
-    tx_ctx *c = server_context(p, prm);
-    std::vector<uint64_t> out(16 * big);
-    if (mini_workload == 1) check(tx_inner_product_u16(c, in.data(), nvals, out.data()), "tx_inner_product_u16");
-    else check(tx_max_u16(c, in.data(), nvals, out.data()), "tx_max_u16");
-    tx_destroy(c);
-    write_words(p.io + "/ciphertexts_download/result.bin", out);
+    Mapped in; in.open(p.io + "/ciphertext_aes_download/result.bin");
+    const size_t big = (size_t)prm.k * prm.N + 1, v16 = 16 * big, nvals = in.size() / v16;
+    if (nvals == 0 || in.size() != nvals * v16) throw std::runtime_error("lwe_ciphertext_list length is not a multiple of 16");
+    if (mini_workload == 1 && (nvals & 1)) throw std::runtime_error("the inner product needs an even number of values");
+    EvalKeyFiles keys; keys.open(p, prm);
+    clk.mark("files_mapped");
+    // max: a device needs two values to compare; inner product: one pair
+    const std::vector<int> devs = device_list(std::max<size_t>(1, nvals / 2));
+    const size_t D = devs.size();
+    std::vector<tx_ctx *> ctx(D, nullptr);
+    std::vector<uint64_t> part(D * v16), outv(v16);
+    std::vector<char> have(D, 0);
+    struct Release { std::vector<tx_ctx *> &c; ~Release() { for (auto x : c) if (x) tx_destroy(x); } } release{ ctx };
+    on_threads(D, [&](size_t r) {
+        const std::string tag = D > 1 ? "[" + std::to_string(r) + "]" : "";
+        ctx[r] = make_context(prm, devs[r], keys);
+        clk.mark("keys_resident" + tag);
+        uint64_t *dst = D == 1 ? outv.data() : part.data() + r * v16;
+        if (mini_workload == 1) {
+            // pairs (q, q + n/2), q in this part's slab: the two operand runs go to device memory where the result file's pages
+            // lie (no host copy), the circuit reads them there
+            const size_t half = nvals / 2;
+            size_t q0, qc; slab(half, D, r, q0, qc);
+            if (qc == 0) return;
+            if (D == 1) { check(tx_inner_product_u16(ctx[r], in.data(), nvals, dst), "tx_inner_product_u16"); have[r] = 1; return; }
+            uint64_t *dev = (uint64_t *)tx_device_alloc(ctx[r], 2 * qc * v16 * 8);
+            if (!dev) throw std::runtime_error(std::string("tx_device_alloc: ") + tx_last_error());
+            int rc = tx_device_upload(ctx[r], dev, in.data() + q0 * v16, qc * v16 * 8);
+            if (!rc) rc = tx_device_upload(ctx[r], dev + qc * v16, in.data() + (half + q0) * v16, qc * v16 * 8);
+            if (!rc) rc = tx_inner_product_u16_io(ctx[r], dev, 2 * qc, dst, 1, 0);
+            const std::string err = rc ? tx_last_error() : "";
+            tx_device_free(ctx[r], dev);
+            if (rc) throw std::runtime_error("tx_inner_product_u16_io: " + err);
+        } else {
+            size_t v0, vc; slab(nvals, D, r, v0, vc);
+            if (vc == 0) return;
+            check(tx_max_u16(ctx[r], in.data() + v0 * v16, vc, dst), "tx_max_u16");
+        }
+        have[r] = 1;
+        clk.mark("part_done" + tag);
+    });
+    if (D > 1) {
+        // one more call of the same circuit over the parts, on the first context ("finish log2(G) comparator
+        // levels on rank 0"; python/txdist.py max_sharded / inner_product_sharded are the multi-process form of this)
+        std::vector<uint64_t> fin;
+        size_t m = 0;
+        for (size_t r = 0; r < D; r++) if (have[r]) { fin.insert(fin.end(), part.begin() + r * v16, part.begin() + (r + 1) * v16); m++; }
+        if (m == 0) throw std::runtime_error("no part produced a result");
+        if (m == 1) std::copy(fin.begin(), fin.end(), outv.begin());
+        else if (mini_workload == 1) {
+            // sum of the partial sums s_0 .. s_{m-1} = inner product of (s_0 .. s_{m-1}) with (1 .. 1), the ones being trivial
+            // ciphertexts: value 1, MSB first = only bit 15 set, body 2^63, mask 0
+            fin.resize(2 * m * v16, 0);
+            for (size_t j = 0; j < m; j++) fin[(m + j) * v16 + 15 * big + (big - 1)] = (uint64_t)1 << 63;
+            check(tx_inner_product_u16(ctx[0], fin.data(), 2 * m, outv.data()), "tx_inner_product_u16 (sum of the parts)");
+        } else
+            check(tx_max_u16(ctx[0], fin.data(), m, outv.data()), "tx_max_u16 (maximum of the parts)");
+        clk.mark("parts_combined");
+    }
+    write_words(p.io + "/ciphertexts_download/result.bin", outv);
+    clk.mark("done");
+    clk.report("server_encrypted_compute", size, D);
     return 0;
 }
 

@@ -251,7 +251,7 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
     """the entry points added in round 4 fail with a message (never crash, never touch a device) on null contexts / pointers"""
     import txhip
     L = txhip.lib()
-    assert L.tx_timing_size() == C.sizeof(txhip.TxTiming) == 112
+    assert L.tx_timing_size() == C.sizeof(txhip.TxTiming) == 120        # round 5: + timing_failed
     assert not L.tx_device_alloc(None, 1024) and b"null context" in L.tx_last_error()
     assert L.tx_device_free(None, None) < 0 and L.tx_device_upload(None, None, None, 8) < 0 and L.tx_device_download(None, None, None, 8) < 0
     assert L.tx_max_u16_io(None, None, 4, None, 1, 1) < 0 and b"tx_max_u16" in L.tx_last_error()
@@ -263,3 +263,54 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.tx_ctr_shared_columns(iv, 0, (1 << 29) + 1, None, None) < 0
     one = (C.c_int * 4)(); two = (C.c_int * 4)()
     assert L.tx_ctr_shared_columns(iv, 0, (1 << 29) + 1, one, two) < 0 and b"does not fit" in L.tx_last_error()
+
+
+def test_round5_entry_points_without_a_gpu():
+    """the entry points added in round 5 (pipelined host output, column-sharing switch, page-locked memory, device count) fail
+    with a message on null arguments and never crash; the chunk size is the documented constant"""
+    import txhip
+    L = txhip.lib()
+    assert L.tx_chunk_blocks() == 128
+    cb = txhip.CHUNK_FN(lambda u, a, b: None)
+    assert L.tx_transcipher_chunks(None, None, 1, None, None, 0, cb, None) < 0 and b"null argument" in L.tx_last_error()
+    assert L.tx_set_ctr_column_sharing(None, 0) < 0 and b"null context" in L.tx_last_error()
+    assert L.tx_host_free(None) == 0
+    n = L.tx_device_count()
+    import torch
+    if not torch.cuda.is_available():
+        assert n <= 0 or n == torch.cuda.device_count()
+
+
+def test_product_library_has_no_experiment_surface():
+    """the shipped library holds neither the superseded kernels nor the TX_* environment knobs; the
+    experiment build (same sources, -DTXD_EXPERIMENTS) holds both and exports the same C ABI"""
+    import subprocess
+    import txhip
+    pkg = os.path.join(ROOT, "temp-fhe-transciphering_amd")
+    prod = open(os.path.join(pkg, "libtfhe_mi355x.so"), "rb").read()
+    exp = open(os.path.join(pkg, "libtfhe_mi355x_exp.so"), "rb").read()
+    for knob in (b"TX_BR_VARIANT", b"TX_TRACE_VARIANT", b"TX_SS_VARIANT", b"TX_LUT_VARIANT", b"TX_BR5_WGS", b"TX_TRSS_WGS_PER_CU", b"TX_CTR_SHARE"):
+        assert knob not in prod, knob
+        assert knob in exp, knob
+    assert b"getenv" not in prod                       # the product library reads no environment at all
+    for kernel in (b"k_blind_rotate4", b"k_lut_eval4", b"15k_extract_trace", b"15k_scheme_switch", b"7k_trace"):
+        assert kernel not in prod, kernel
+        assert kernel in exp, kernel
+    for kernel in (b"k_blind_rotate5", b"k_blind_rotate6", b"k_blind_rotate7", b"k_trace_scheme_switch4", b"k_lut_eval", b"k_extract_trace4"):
+        assert kernel in prod, kernel
+    Lx = txhip.lib(experiments=True)
+    for s in declared_symbols():
+        assert hasattr(Lx, s), s
+
+
+def test_stage_device_list_parsing(tmp_path):
+    """TX_DEVICES of the server stages (host/stages.cpp device_list): a malformed list is a usage error (exit 1, message) before
+    any GPU work; the key files are checked before that"""
+    import subprocess
+    exe = os.path.join(ROOT, "temp-fhe-transciphering_amd", "bin", "server_encrypted_aes_decryption")
+    r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot read datasets/toy/db.hex" in r.stderr
+    os.makedirs(tmp_path / "datasets" / "toy")
+    (tmp_path / "datasets" / "toy" / "db.hex").write_text("00" * 16)
+    r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "public_keys/ksk.bin" in r.stderr

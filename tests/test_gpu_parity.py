@@ -120,7 +120,7 @@ def test_lut_tree_kernels_agree(rig256, monkeypatch):
     nbytes = 37
     gf = rng.standard_normal(nbytes * 8 * r.p.cbs_level * 3 * 3 * 1024) * 2.0 ** 40
     monkeypatch.setenv("TX_LUT_VARIANT", "4")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     e0.load_round_luts(r.luts); e0.load_ctr_luts(r.ctr_luts)
     gl = r.octx.gl
@@ -249,18 +249,17 @@ def test_ctr_shared_columns_equal_full_evaluation(rig256, monkeypatch):
     """CTR batches bootstrap each DISTINCT column of their second round once (blocks whose counters agree in the four bytes
     feeding a column hold the same ciphertexts there).  Five blocks whose counters run ..fe, ..ff, then carry into byte 14
     (columns 0 and 1 both change), and a batch whose IV wraps around 2^128: bit-identical to the engine with sharing off
-    (TX_CTR_SHARE=0), to the oracle (which evaluates every column), and block-wise to single-block runs (no sharing
+    (tx_set_ctr_column_sharing(c, 0)), to the oracle (which evaluates every column), and block-wise to single-block runs (no sharing
     possible there)"""
     import txhip
     import txdist
     r = rig256
     rng = np.random.default_rng(55)
     ct = rng.integers(0, 256, 16 * 5, dtype=np.uint8).tobytes()
-    monkeypatch.setenv("TX_CTR_SHARE", "0")
     e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0.set_ctr_column_sharing(False)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     e0.load_ctr_luts(r.ctr_luts)
-    monkeypatch.delenv("TX_CTR_SHARE")
     for iv in (AES_IV[:14] + b"\x07\xfe", bytes([0xFF] * 15) + b"\xfd"):
         shared = r.eng.transcipher(ct, iv=iv)
         assert np.array_equal(shared, e0.transcipher(ct, iv=iv))
@@ -386,8 +385,9 @@ def test_max_single_value_and_chunked_levels(rig256):
 
 
 def test_create_failure_paths_release_the_context(monkeypatch):
-    """tx_create failing behind the stream and the twiddle tables (an ill-formed experiment knob is parsed there)
-    returns NULL with a message and releases what it had built: 200 failures in a row, then a working context"""
+    """tx_create failing behind the stream and the twiddle tables (the experiment build parses its knobs there: an ill-formed
+    one) returns NULL with a message and releases what it had built: 200 failures in a row, then a working context.  The
+    product library reads no environment: the same values leave it unmoved"""
     import txhip
     p = txhip.aes_tight(n=256)
     for name, bad in (("TX_BR_VARIANT", "8"), ("TX_BR_VARIANT", "x"), ("TX_TRSS_WGS_PER_CU", "0"), ("TX_BR5_WGS", "-3"),
@@ -395,7 +395,8 @@ def test_create_failure_paths_release_the_context(monkeypatch):
         monkeypatch.setenv(name, bad)
         for _ in range(34):
             with pytest.raises(txhip.TxError, match="tx_create"):
-                txhip.Engine(p, 0)
+                txhip.Engine(p, 0, experiments=True)
+        txhip.Engine(p, 0).close()                 # the product library does not look at the knobs
         monkeypatch.delenv(name)
     with pytest.raises(txhip.TxError, match="no such HIP device"):
         txhip.Engine(p, 99)
@@ -466,6 +467,115 @@ def test_stage_executables_end_to_end(size, mw, tmp_path):
     import json as _json
     res = _json.load(open(tmp_path / "measurements" / name / "results.json"))
     assert set(res) == {"total_latency_s", "per_stage", "bandwidth"}
+
+
+@pytest.mark.parametrize("size,devices", [(1, "0,0"), (1, "0,0,0"), (2, "0,0"), (3, "0,0")])
+def test_stage_executables_shard_across_devices_in_process(size, devices, tmp_path):
+    """`server_encrypted_aes_decryption <size>` / `server_encrypted_compute <size>` shard the instance
+    across TX_DEVICES in-process (one tx_ctx + one host thread per entry, keys read once from io/<size>/public_keys).  With
+    two contexts on the one card of the box (TX_DEVICES=0,0) every file a later stage or the harness reads equals the
+    single-device run byte for byte: ciphertext_aes_download/result.bin (the slabs are the same blocks, the kernels are
+    deterministic per unit), result_aes.txt, result.txt, and for the max also ciphertexts_download/result.bin (two slabs of
+    a power-of-two instance are the two halves of the same tournament).  The inner product's partial sums are added by one
+    more circuit, so its result CIPHERTEXT differs from the single-device one while result.txt is the same value.  Three
+    contexts on the small instance: ragged slabs (3 + 3 + 2 blocks)."""
+    import subprocess
+    import sys as _sys
+    import filecmp
+    root = os.path.dirname(HERE)
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_submission.py")
+    name = ["toy", "small", "medium", "large"][size]
+    for mw in (0, 1):
+        dirs = {}
+        for tag, dv in (("one", "0"), ("many", devices)):
+            d = tmp_path / f"{tag}{mw}"
+            d.mkdir()
+            env = dict(os.environ, TX_DEVICES=dv, TX_STAGE_TIMING=str(d / "stage_timing.jsonl"))
+            r = subprocess.run([_sys.executable, rs, str(size), "--root", str(d), "--seed", "123", "--fhe_seed", "99",
+                                "--mini_workload", str(mw)], capture_output=True, text=True, timeout=900, env=env)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert ("AES decryption: PASS; inner product: PASS" if mw else "AES decryption: PASS; max: PASS") in r.stdout
+            dirs[tag] = d / "io" / name
+            import json as _json
+            lines = [_json.loads(l) for l in open(d / "stage_timing.jsonl")]
+            assert [l["stage"] for l in lines] == ["server_encrypted_aes_decryption", "server_encrypted_compute"]
+            assert lines[0]["devices"] == len(dv.split(","))
+        same = ["ciphertext_aes_download/result.bin", "result_aes.txt", "result.txt"]
+        if mw == 0 and devices == "0,0":
+            same.append("ciphertexts_download/result.bin")
+        for f in same:
+            assert filecmp.cmp(dirs["one"] / f, dirs["many"] / f, shallow=False), f
+        if size == 3:                      # 2 x 1 GB of result LWEs per pair of runs: make room for the second mini-workload
+            import shutil
+            shutil.rmtree(tmp_path / f"one{mw}"); shutil.rmtree(tmp_path / f"many{mw}")
+
+
+def test_stage_rejects_a_bad_device_list(tmp_path):
+    """a malformed or out-of-range TX_DEVICES is exit status 1 with a message (the harness aborts: check=True), never a crash"""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(HERE)
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_submission.py")
+    r = subprocess.run([_sys.executable, rs, "0", "--root", str(tmp_path), "--seed", "5", "--fhe_seed", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = os.path.join(root, "temp-fhe-transciphering_amd", "bin", "server_encrypted_aes_decryption")
+    for bad, msg in (("0,,1", "not a comma-separated list"), ("a", "not a comma-separated list"), ("0,", "ends with a comma"), ("99", "no such HIP device")):
+        r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, TX_DEVICES=bad), timeout=120)
+        assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr)
+
+
+def test_host_output_is_pipelined_chunk_by_chunk(rig256):
+    """tx_transcipher_chunks (round 5): 300 blocks = chunks of 128 + 128 + 44; the callback sees every chunk once, in order,
+    AFTER its LWEs have arrived in the caller's memory (page-locked or pageable), and the result equals tx_transcipher's;
+    a device-resident result takes the same callbacks"""
+    r = rig256
+    rng = np.random.default_rng(78)
+    ct = rng.integers(0, 256, 16 * 300, dtype=np.uint8).tobytes()
+    want = r.eng.transcipher(ct, iv=AES_IV)
+    for pinned in (True, False):
+        got, seen, arrived = r.eng.transcipher_chunks(ct, iv=AES_IV, pinned=pinned)
+        assert seen == [(0, 128), (128, 128), (256, 44)] and all(arrived), (pinned, seen, arrived)
+        assert np.array_equal(got, want)
+    one, seen, arrived = r.eng.transcipher_chunks(ct[:16 * 5], iv=AES_IV)
+    assert seen == [(0, 5)] and all(arrived) and np.array_equal(one, want[:5 * 128])
+
+
+def test_two_contexts_driven_from_two_threads(rig256):
+    """include/tfhe_mi355x.h: distinct contexts may be driven concurrently from distinct threads (ctypes releases the GIL
+    during a call): two contexts on the one card, each transciphering its own blocks at the same time, give what one context
+    gives alone; each thread reads its OWN error text"""
+    import threading
+    import txhip
+    r = rig256
+    rng = np.random.default_rng(79)
+    cts = [rng.integers(0, 256, 16 * 6, dtype=np.uint8).tobytes() for _ in range(2)]
+    want = [r.eng.transcipher(c, iv=AES_IV) for c in cts]
+    engs = []
+    for _ in range(2):
+        e = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+        e.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+        e.load_ctr_luts(r.ctr_luts)
+        engs.append(e)
+    got, errs = [None, None], [None, None]
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = engs[i].transcipher(cts[i], iv=AES_IV)
+            if i == 1:
+                try:
+                    engs[i].load_round_luts(r.luts[:-1])
+                except txhip.TxError as ex:
+                    errs[i] = str(ex)
+        except Exception as ex:          # noqa: BLE001
+            errs[i] = "unexpected: %r" % (ex,)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert errs[0] is None and "wrong size" in errs[1]
+    for i in range(2):
+        assert np.array_equal(got[i], want[i])
+        engs[i].close()
 
 
 def test_chunked_batches_match_unchunked(rig256):
@@ -574,7 +684,7 @@ def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monk
     lwe[2, :] = 0
     ref = r.octx.blind_rotate(lwe)
     monkeypatch.setenv("TX_BR_VARIANT", variant)
-    e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)      # 13 units: a ragged last workgroup
+    e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)      # 13 units: a ragged last workgroup
     e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     got = e4.blind_rotate(lwe)
     assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6", "7": "k_blind_rotate7"}[variant]
@@ -597,7 +707,7 @@ def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
     cnt = 1024
     lwe = rng.integers(0, 1 << 63, (cnt, r.p.n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (cnt, r.p.n + 1), dtype=np.uint64)
     monkeypatch.setenv("TX_BR_VARIANT", "0")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     one_wave = e0.blind_rotate(lwe)
     assert e0.last_blind_rotate_kernel() == "k_blind_rotate"
@@ -608,7 +718,7 @@ def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
     assert np.array_equal(r.eng.blind_rotate(lwe[:1021]), one_wave[:1021])
     assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate7"
     monkeypatch.setenv("TX_BR_VARIANT", "6")
-    e6 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e6 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e6.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     coop = e6.blind_rotate(lwe)
     assert e6.last_blind_rotate_kernel() == "k_blind_rotate6"
@@ -634,7 +744,7 @@ def test_blind_rotation_dispatch_by_launch_size(rig256, monkeypatch):
     auto = r.eng.blind_rotate(lwe)
     assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate5"
     monkeypatch.setenv("TX_BR_VARIANT", "0")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     one_wave = e0.blind_rotate(lwe)
     assert e0.last_blind_rotate_kernel() == "k_blind_rotate"
@@ -653,7 +763,7 @@ def test_trace_kernels_agree(rig256, monkeypatch):
     acc = rng.integers(0, 1 << 63, (9, 3, 1024), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (9, 3, 1024), dtype=np.uint64)
     new = r.eng.extract_trace(acc)                      # 63 units: the last workgroup has one idle wave
     monkeypatch.setenv("TX_TRACE_VARIANT", "0")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     old = e0.extract_trace(acc)
     e0.close()
@@ -670,7 +780,7 @@ def test_scheme_switch_kernels_agree(rig256, monkeypatch):
     glev = rng.integers(0, 1 << 63, (5, r.p.cbs_level, 3, 1024), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (5, r.p.cbs_level, 3, 1024), dtype=np.uint64)
     new = r.eng.scheme_switch_fourier(glev)              # 35 units: the last workgroup has one idle wave
     monkeypatch.setenv("TX_SS_VARIANT", "0")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     old = e0.scheme_switch_fourier(glev)
     e0.close()
@@ -724,7 +834,7 @@ def test_circuit_bootstrap_fused_kernel_at_depth(rig256, monkeypatch):
     assert np.array_equal(fused[pick].reshape(len(pick), -1).view(np.uint64), np.asarray(want).reshape(len(pick), -1).view(np.uint64))
     monkeypatch.setenv("TX_TRACE_VARIANT", "0")
     monkeypatch.setenv("TX_SS_VARIANT", "0")
-    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e0 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e0.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     sep = e0.circuit_bootstrap(lwe)
     t0 = e0.timing()
