@@ -75,6 +75,12 @@ int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t bsk_words, const ui
 /* the word counts tx_load_eval_keys expects for this context (in the order bsk, ksk, auto, ss) */
 int tx_eval_key_words(const tx_ctx *c, size_t out4[4]);
 
+/* Announces the size of the instances to come (AES blocks per call; more than tx_chunk_blocks() is the same as that many): the
+ * workspace -- 0.1 GB per block, sized to the instance, not to the chunk limit -- is then allocated by tx_load_eval_keys
+ * underneath the key transforms (or at once if the keys are resident) instead of inside the first tx_transcipher call.
+ * Optional: every call grows the workspace on demand. */
+int tx_reserve(tx_ctx *c, size_t n_blocks);
+
 /* `AllRdKeys` (submission/src/data_struct.rs:10-26; trans_key.bin, SRV_AES :635) as one blob:
  * [set 0..8][mult x9,x11,x13,x14][byte 16][acc 2][K][N] then round 0 [byte 16][acc 2][K][N];
  * set 0 = fused rounds 10/9, sets 1..8 = rounds 8..1.  words = (9*4+1)*16*2*K*N. */
@@ -114,6 +120,11 @@ int tx_set_ctr_column_sharing(tx_ctx *c, int enabled);
  * are written by DMA at link speed instead of through the runtime's staging copies.  No context needed; NULL on failure. */
 void *tx_host_alloc(size_t bytes);
 int   tx_host_free(void *p);
+/* The same for memory the caller already has (a region of an anonymous mapping, a buffer of the host language's allocator):
+ * page-locks [p, p + bytes) for every device (hipHostRegister, portable).  A large result can be pinned region by region while
+ * earlier chunks compute -- a copy whose destination is not (yet) registered is still correct, only slower. */
+int   tx_host_register(void *p, size_t bytes);
+int   tx_host_unregister(void *p);
 /* number of HIP devices visible to the process (what the stage executables shard across by default); negative on error */
 int   tx_device_count(void);
 

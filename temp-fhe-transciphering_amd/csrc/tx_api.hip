@@ -29,6 +29,8 @@ extern "C" const char *tx_last_error(void) { return g_err.c_str(); }
             return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
+static const size_t CHUNK_BLOCKS = 128;     // blocks per workspace chunk (16 384 bit ciphertexts: 8.4 GB of Fourier GGSWs)
+
 enum Family { F_KS = 0, F_BR, F_TRACE, F_SS, F_LUT, F_LIN, F_COUNT };
 
 struct tx_ctx {
@@ -65,6 +67,7 @@ struct tx_ctx {
     bool have_keys = false;
     // workspace (grown on demand)
     size_t ws_blocks = 0, glev_bits = 0;
+    size_t reserve_blocks = 0;              // tx_reserve: blocks per chunk the next calls will need (allocated with the keys, or at once)
     uint64_t *st = nullptr, *sm = nullptr, *small = nullptr, *acc = nullptr, *glev = nullptr, *res = nullptr;
     cplx *ggsw_f = nullptr;
     uint8_t *d_bytes = nullptr, *d_ct = nullptr;
@@ -394,6 +397,18 @@ extern "C" int tx_host_free(void *p)
     HIP_OK(hipHostFree(p));
     return 0;
 }
+extern "C" int tx_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return fail("tx_host_register: null argument");
+    HIP_OK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return 0;
+}
+extern "C" int tx_host_unregister(void *p)
+{
+    if (!p) return 0;
+    HIP_OK(hipHostUnregister(p));
+    return 0;
+}
 extern "C" int tx_device_count(void)
 {
     int n = 0;
@@ -409,9 +424,10 @@ struct DevBuf {
 };
 
 // ---- key loading (SRV_AES:640-687) ----
-static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst, int mode)
+// Uploads and transforms are enqueued on the context's stream and NOT waited for here: tx_load_eval_keys synchronises once at
+// its end, and allocates in between (staging buffers are released after that synchronisation).
+static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst, int mode, DevBuf &buf)
 {
-    DevBuf buf;
     if (buf.alloc(words * 8)) return fail("fwd_polys: hipMalloc failed");
     uint64_t *tmp = (uint64_t *)buf.p;
     HIP_OK(hipMemcpyAsync(tmp, h_src, words * 8, hipMemcpyHostToDevice, c->stream));
@@ -423,7 +439,6 @@ static int fwd_polys(tx_ctx *c, const uint64_t *h_src, size_t words, cplx *d_dst
                            d_dst + c->auto_split_stride, npoly, 2, (int)AUTO_SPLIT, c->tw);
     }
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -433,6 +448,8 @@ extern "C" int tx_eval_key_words(const tx_ctx *c, size_t out4[4])
     out4[0] = bsk_words(c->p); out4[1] = ksk_words(c->p); out4[2] = auto_words(); out4[3] = ss_words();
     return 0;
 }
+
+static int ensure_ws(tx_ctx *c, size_t nb);
 
 extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t n_bsk, const uint64_t *ksk, size_t n_ksk,
                                  const uint64_t *auto_keys, size_t n_auto, const uint64_t *ss_key, size_t n_ss)
@@ -445,6 +462,7 @@ extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t n_bsk, c
                     std::to_string(na) + ", ss " + std::to_string(n_ss) + "/" + std::to_string(ns) +
                     " words given/expected for n = " + std::to_string(c->p.n) + ")");
     HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
     c->bsk_f = c->ksk_f = c->auto_f = c->ss_f = nullptr; c->have_keys = false;
     HIP_OK(hipMalloc(&c->bsk_f, nb * 8));
@@ -452,19 +470,26 @@ extern "C" int tx_load_eval_keys(tx_ctx *c, const uint64_t *bsk, size_t n_bsk, c
     HIP_OK(hipMalloc(&c->auto_f, na * 8 * 2));
     HIP_OK(hipMalloc(&c->ss_f, ns * 8));
     c->auto_split_stride = na / 2;                                  // complex units per split
-    if (fwd_polys(c, bsk, nb, c->bsk_f, 0)) return -1;
-    if (fwd_polys(c, auto_keys, na, c->auto_f, 1)) return -1;
-    if (fwd_polys(c, ss_key, ns, c->ss_f, 0)) return -1;
-    {
-        DevBuf buf;
-        if (buf.alloc(nk * 8)) return fail("tx_load_eval_keys: hipMalloc failed");
-        uint64_t *tmp = (uint64_t *)buf.p;
-        HIP_OK(hipMemcpyAsync(tmp, ksk, nk * 8, hipMemcpyHostToDevice, c->stream));
-        int npoly = (int)(nk / KS_N);
-        hipLaunchKernelGGL(k_fwd_torus256, dim3(grid_for(npoly)), dim3(256), 0, c->stream, tmp, c->ksk_f, npoly, c->tw256);
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(c->stream));
+    DevBuf s_bsk, s_auto, s_ss, s_ksk;                              // staging, alive until the synchronisation below
+    int rc = fwd_polys(c, bsk, nb, c->bsk_f, 0, s_bsk);
+    if (!rc) rc = fwd_polys(c, auto_keys, na, c->auto_f, 1, s_auto);
+    if (!rc) rc = fwd_polys(c, ss_key, ns, c->ss_f, 0, s_ss);
+    if (!rc) {
+        if (s_ksk.alloc(nk * 8)) rc = fail("tx_load_eval_keys: hipMalloc failed");
+        else {
+            uint64_t *tmp = (uint64_t *)s_ksk.p;
+            if (hipMemcpyAsync(tmp, ksk, nk * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail("tx_load_eval_keys: upload failed");
+            else {
+                int npoly = (int)(nk / KS_N);
+                hipLaunchKernelGGL(k_fwd_torus256, dim3(grid_for(npoly)), dim3(256), 0, c->stream, tmp, c->ksk_f, npoly, c->tw256);
+                if (hipGetLastError() != hipSuccess) rc = fail("tx_load_eval_keys: launch failed");
+            }
+        }
     }
+    // a reservation made before the keys arrived (tx_reserve) is filled while the transforms run
+    if (!rc && c->reserve_blocks > c->ws_blocks) rc = ensure_ws(c, c->reserve_blocks);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("tx_load_eval_keys: hipStreamSynchronize failed");
+    if (rc) return -1;
     c->have_keys = true;
     return 0;
 }
@@ -485,6 +510,15 @@ extern "C" int tx_load_ctr_luts(tx_ctx *c, const uint64_t *luts, size_t words)
 { return load_blob(c, c ? &c->ctr_luts : nullptr, luts, words, ctr_lut_words(), "tx_load_ctr_luts"); }
 
 // ---- workspace ----
+extern "C" int tx_reserve(tx_ctx *c, size_t n_blocks)
+{
+    if (!c) return fail("tx_reserve: null context");
+    c->reserve_blocks = std::min(n_blocks, CHUNK_BLOCKS);
+    if (!c->have_keys || c->reserve_blocks <= c->ws_blocks) return 0;      // without keys: allocated under their transforms
+    HIP_OK(hipSetDevice(c->device));
+    return ensure_ws(c, c->reserve_blocks);
+}
+
 static int ensure_ws(tx_ctx *c, size_t nb)
 {
     if (nb <= c->ws_blocks) return 0;
@@ -835,8 +869,6 @@ static int transcipher_chunk(tx_ctx *c, const uint8_t *ct, size_t nb, const uint
     HIP_OK(hipGetLastError());
     return 0;
 }
-
-static const size_t CHUNK_BLOCKS = 128;
 
 // Host output (round 5): the chunks' results alternate between two device buffers; chunk k's LWEs travel to the caller's
 // memory on copy_stream while chunk k + 1 computes, and `cb` (may be null) is called on the calling thread for every chunk

@@ -469,7 +469,11 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
     const uint32_t cu8 = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);
     uint32_t *fair_entry = fair_tab + (size_t)(((xcc & 15u) << 8) | (cu8 & 255u)) * FAIR_TAB_WORDS;
-    if (threadIdx.x == 0) fair_slot = atomicAdd(fair_entry + 4, 1u) & 3u;      // consecutive draws: four distinct words
+    // consecutive draws: distinct words for the FIRST four workgroups a CU hosts in a launch.  A later arrival (a CU hosts 5-7
+    // workgroups in turn when the placement is late) may draw the word of a workgroup that is still running; the two then
+    // overwrite each other's step counters and a finisher's 0xFFFF marker may briefly stand in a runner's word.  Only
+    // s_setprio is affected -- never a result -- and the arbitration is noisier in exactly that case.
+    if (threadIdx.x == 0) fair_slot = atomicAdd(fair_entry + 4, 1u) & 3u;
     unsigned char *tile0 = lds + BR3_TW_CPLX * sizeof(cplx);
     unsigned char *tile = tile0 + (size_t)wave * BR3_TILE_BYTES;
     uint64_t *pl = reinterpret_cast<uint64_t *>(tile);
@@ -539,6 +543,9 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // every barrier): they compute and store the same words.
 // ------------------------------------------------------------------------------------------
 constexpr int BR7_UNITS = 4;
+// The generated loop derives its key-prefetch dump area from TILE0 + 3 tiles; here that is the NEXT unit's first tile.  The
+// committed stream has no prefetch (BR3_PF_ROWS = 0): regenerating with one would corrupt three of every four units.
+static_assert(BR6_PF_ROWS == 0, "k_blind_rotate7 passes the unit's own tiles as TILE0: a key prefetch would dump into the next unit's tile");
 constexpr size_t LDS_BYTES_BR7 = BR3_TW_CPLX * sizeof(cplx) + BR7_UNITS * BR6_WAVES * BR3_TILE_BYTES + 1024;
 
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -704,8 +711,8 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
     unsigned char *tile = tr4_setup(lds, tw_g, wave, slot0);
     const int lane = threadIdx.x & 63;
     int unit = blockIdx.x * WAVES + wave;
-    const bool active = unit < count * CBS_L;       // idle waves of the last workgroup redo the last unit (in their
-    if (!active) unit = count * CBS_L - 1;          // own LDS): every wave takes part in the key ring's barriers
+    const bool active = unit < count * CBS_L;       // idle waves of the last workgroup redo the last unit (in their own LDS):
+    if (!active) unit = count * CBS_L - 1;          // needed by the ring form of the loop (barriers); harmless with streamed keys
     uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
     tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
     tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, lds_addr(slot0), lds_addr(tile));

@@ -261,10 +261,11 @@ struct EvalKeyFiles {
             ss.size() != txc_ss_words(&prm)) throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set");
     }
 };
-tx_ctx *make_context(const tx_params &prm, int dev, const EvalKeyFiles &k)
+tx_ctx *make_context(const tx_params &prm, int dev, const EvalKeyFiles &k, size_t reserve_blocks = 0)
 {   // SRV_AES:646-687: conversion of the keys to their evaluation form, here on the GPU, once per context
     tx_ctx *c = tx_create(&prm, dev);
     if (!c) throw std::runtime_error(std::string("tx_create (device ") + std::to_string(dev) + "): " + tx_last_error());
+    if (reserve_blocks) tx_reserve(c, reserve_blocks);       // the workspace is then allocated underneath the key transforms
     if (tx_load_eval_keys(c, k.bsk.data(), k.bsk.size(), k.ksk.data(), k.ksk.size(), k.au.data(), k.au.size(), k.ss.data(), k.ss.size())) {
         std::string m = std::string("tx_load_eval_keys: ") + tx_last_error();
         tx_destroy(c);
@@ -319,6 +320,33 @@ struct ResultFile {
     ~ResultFile() { if (fd >= 0) close(fd); }
 };
 
+// Landing area of a slab's result LWEs: an anonymous mapping, page-locked REGION BY REGION (one workspace chunk each) on a
+// thread of its own -- the first region while the context is built and the keys are transformed, region k while chunk k - 1
+// computes.  Pinning costs about 0.28 s per GB and holds a lock of the HIP runtime: all at once it would stand in front of the
+// first kernel of a large instance.  A copy into a region that is not pinned yet is still correct (staged by the runtime).
+struct Landing {
+    uint64_t *base = nullptr; size_t bytes = 0, region = 0;
+    std::atomic<size_t> pinned{0};
+    std::atomic<bool> failed{false};
+    std::thread th;
+    void start(size_t total_bytes, size_t region_bytes)
+    {
+        bytes = total_bytes; region = region_bytes;
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::runtime_error("cannot map the result buffer");
+        base = (uint64_t *)m;
+        th = std::thread([this] {
+            for (size_t o = 0; o < bytes; o += region) {
+                if (tx_host_register((char *)base + o, std::min(region, bytes - o)) != 0) { failed = true; return; }
+                pinned = o + std::min(region, bytes - o);
+            }
+        });
+    }
+    void wait_first() { while (!failed && pinned.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+    void finish() { if (th.joinable()) th.join(); }
+    ~Landing() { finish(); }        // (the mapping and its registrations go with the process)
+};
+
 int server_encrypted_aes_decryption(int size)
 {   // SRV_AES:599-707, all blocks of db.hex
     Clock clk;
@@ -340,21 +368,19 @@ int server_encrypted_aes_decryption(int size)
         size_t b0, cnt; slab(nb, D, r, b0, cnt);
         if (cnt == 0) return;
         const std::string tag = D > 1 ? "[" + std::to_string(r) + "]" : "";
-        // page-locked landing area of this slab: allocated on a thread of its own while the context is built and the keys are
-        // transformed (pinning 134 MB costs as much as uploading the keys)
-        uint64_t *host = nullptr; std::string host_err;
-        std::thread pin([&] { host = (uint64_t *)tx_host_alloc(cnt * blkw * 8); if (!host) host_err = tx_last_error(); });
+        Landing land;
+        land.start(cnt * blkw * 8, std::min(cnt, tx_chunk_blocks()) * blkw * 8);
+        uint64_t *host = land.base;
         tx_ctx *c = nullptr;
         try {
-            c = make_context(prm, devs[r], keys);
+            c = make_context(prm, devs[r], keys, cnt);
             clk.mark("keys_resident" + tag);
             if (size == 0) check(tx_load_round_luts(c, luts.data(), luts.size()), "tx_load_round_luts");
             else check(tx_load_ctr_luts(c, luts.data(), luts.size()), "tx_load_ctr_luts");
             clk.mark("luts_resident" + tag);
-        } catch (...) { pin.join(); tx_host_free(host); if (c) tx_destroy(c); throw; }
-        pin.join();
-        if (!host) { tx_destroy(c); throw std::runtime_error("tx_host_alloc: " + host_err); }
-        clk.mark("pinned" + tag);
+        } catch (...) { land.finish(); if (c) tx_destroy(c); throw; }
+        land.wait_first();
+        clk.mark("first_region_pinned" + tag);
         uint8_t iv_r[16];
         if (size != 0) iv_add(iv.data(), b0, iv_r);
         Part part{ &out, host, b0, blkw };
@@ -369,9 +395,10 @@ int server_encrypted_aes_decryption(int size)
             }, &cb);
         const std::string err = rc ? std::string("tx_transcipher: ") + tx_last_error() : cb_err;
         clk.mark("transciphered" + tag);
-        tx_destroy(c);
-        tx_host_free(host);
-        if (!err.empty()) throw std::runtime_error(err);
+        land.finish();
+        if (!err.empty()) { tx_destroy(c); throw std::runtime_error(err); }
+        // (the context, its 0.1 GB per block of workspace and the landing area are released by the process's exit: main leaves
+        // through _exit once the result file is closed)
     });
     out.finish();
     clk.mark("done");
@@ -397,7 +424,7 @@ int server_encrypted_compute(int size, int mini_workload)
     std::vector<tx_ctx *> ctx(D, nullptr);
     std::vector<uint64_t> part(D * v16), outv(v16);
     std::vector<char> have(D, 0);
-    struct Release { std::vector<tx_ctx *> &c; ~Release() { for (auto x : c) if (x) tx_destroy(x); } } release{ ctx };
+    struct Release { std::vector<tx_ctx *> &c; bool armed = true; ~Release() { if (armed) for (auto x : c) if (x) tx_destroy(x); } } release{ ctx };
     on_threads(D, [&](size_t r) {
         const std::string tag = D > 1 ? "[" + std::to_string(r) + "]" : "";
         ctx[r] = make_context(prm, devs[r], keys);
@@ -447,6 +474,7 @@ int server_encrypted_compute(int size, int mini_workload)
     write_words(p.io + "/ciphertexts_download/result.bin", outv);
     clk.mark("done");
     clk.report("server_encrypted_compute", size, D);
+    release.armed = false;          // success: the contexts go with the process (main leaves through _exit)
     return 0;
 }
 
@@ -463,10 +491,14 @@ int main(int argc, char **argv)
         if (name == "client_preprocess" || name == "server_preprocess_dataset") return 0;   // stubs in the reference too
         if (name == "client_key_generation") return client_key_generation(size);
         if (name == "client_encode_encrypt") return client_encode_encrypt(size);
-        if (name == "server_encrypted_aes_decryption") return server_encrypted_aes_decryption(size);
+        // The server stages leave through _exit once their result file is written and closed: tearing down the HIP runtime and
+        // returning several GB of device memory piece by piece costs 50 ms of a stage the harness clocks as a whole process
+        // (harness/utils.py:85-109); the driver reclaims everything when the process ends.
+        auto leave = [](int rc) { fflush(stdout); fflush(stderr); _exit(rc); return rc; };
+        if (name == "server_encrypted_aes_decryption") return leave(server_encrypted_aes_decryption(size));
         if (name == "server_encrypted_compute") {   // optional 2nd argument / TX_MINI_WORKLOAD: 0 = max, 1 = inner product
             const int mw = argc > 2 ? std::stoi(argv[2]) : (getenv("TX_MINI_WORKLOAD") ? atoi(getenv("TX_MINI_WORKLOAD")) : 0);
-            return server_encrypted_compute(size, mw);
+            return leave(server_encrypted_compute(size, mw));
         }
         if (name == "client_decrypt_decode_aes_decryption") return client_decrypt(size, "ciphertext_aes_download", "decoded_result_aes.txt");
         if (name == "client_postprocess_aes_decryption") return client_postprocess(size, "decoded_result_aes.txt", "result_aes.txt");

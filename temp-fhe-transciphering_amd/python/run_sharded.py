@@ -9,6 +9,12 @@ or  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 
 (the first form starts its own N rank processes before it has made any GPU call and fails fast on a node with fewer GPUs;
 --force-dist sends a single rank through the process group and every collective as well)
 
+--io ROOT: SERVER mode behind the harness's io/ contract (harness/run_submission.py:91-99): instead of generating a workload and
+keys of its own, every rank reads datasets/<size>/{db.hex,aes_iv.hex} and the files the client stages wrote under
+ROOT/io/<size>/ (public_keys/*.bin, ciphertexts_upload/trans_key.bin), and rank 0 writes what the two server stages write:
+ciphertext_aes_download/result.bin and ciphertexts_download/result.bin (mini-workload --mini_workload / TX_MINI_WORKLOAD).  It is the
+multi-PROCESS form of what `server_encrypted_aes_decryption` + `server_encrypted_compute` do in-process over TX_DEVICES.
+
 One process per GPU, a full replica of the evaluation keys on each (same FHE seed, no broadcast), contiguous
 slabs of AES blocks per rank; no collective on the data path of the transcipher.  Exchanges: one gather of the
 result LWEs, one gather of the partial maxima, and for the inner product one point-to-point step that brings
@@ -41,6 +47,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=0,
                     help="started as a plain command (no RANK in the environment): launch this many ranks as child processes")
     ap.add_argument("--force-dist", action="store_true", help="a single rank still initialises the process group and takes every collective")
+    ap.add_argument("--io", default=None, metavar="ROOT",
+                    help="server mode: inputs from ROOT/datasets/<size>/ and ROOT/io/<size>/ as the client stages left them, results "
+                         "written where the two server stages write them (no workload or keys generated here)")
+    ap.add_argument("--mini_workload", type=int, default=int(os.environ.get("TX_MINI_WORKLOAD", "0")), choices=[0, 1],
+                    help="--io: which result goes to ciphertexts_download/result.bin (0 = max, 1 = inner product; both are computed)")
     args = ap.parse_args()
 
     import txdist
@@ -77,26 +88,36 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     d = dist if use_dist else None
 
-    np.random.seed(args.seed)
-    db = np.random.randint(0, 65536, size=DB_BOUND[args.size], dtype=np.uint16)
-    if args.values:
-        if args.values % 8 or args.values > len(db):
-            raise SystemExit("--values must be a multiple of 8 (whole AES blocks) within the instance")
-        db = db[: args.values]
-    key = hashlib.sha256(str(args.seed).encode()).digest()[:16]
-    iv = hashlib.sha256(b"iv" + str(args.seed).encode()).digest()[:16] if args.size else None
-    pt = b"".join(int(v).to_bytes(2, "big") for v in db)
-    ct = txclient.aes_ctr_crypt(key, iv, pt) if args.size else txclient.aes_ecb_encrypt(key, pt)
-    n_blocks, n_values = len(ct) // 16, len(db)
-
     p = txhip.aes_tight(n=args.n)
-    keys = txclient.ClientKeys(p, seed=args.fhe_seed)
+    name = ["toy", "small", "medium", "large"][args.size]
+    if args.io:
+        # server mode: what a server that received the client's files does -- nothing is generated here
+        data, io_dir = os.path.join(args.io, "datasets", name), os.path.join(args.io, "io", name)
+        ct = bytes.fromhex(open(os.path.join(data, "db.hex")).read().strip())
+        iv = bytes.fromhex(open(os.path.join(data, "aes_iv.hex")).read().strip()) if args.size else None
+        if not ct or len(ct) % 16:
+            raise SystemExit("db.hex must hold whole 16-byte blocks")
+        keys = txclient.StageKeys(p, io_dir)
+        exp = os.path.join(data, "expected_aes.txt")        # the harness's cleartext result, if it is there (a one-machine run)
+        db = np.array([int(x) for x in open(exp).read().split()], np.uint16) if (keys.glwe_sk is not None and os.path.exists(exp)) else None
+        n_blocks, n_values = len(ct) // 16, len(ct) // 2
+    else:
+        np.random.seed(args.seed)
+        db = np.random.randint(0, 65536, size=DB_BOUND[args.size], dtype=np.uint16)
+        if args.values:
+            if args.values % 8 or args.values > len(db):
+                raise SystemExit("--values must be a multiple of 8 (whole AES blocks) within the instance")
+            db = db[: args.values]
+        key = hashlib.sha256(str(args.seed).encode()).digest()[:16]
+        iv = hashlib.sha256(b"iv" + str(args.seed).encode()).digest()[:16] if args.size else None
+        pt = b"".join(int(v).to_bytes(2, "big") for v in db)
+        ct = txclient.aes_ctr_crypt(key, iv, pt) if args.size else txclient.aes_ecb_encrypt(key, pt)
+        n_blocks, n_values = len(ct) // 16, len(db)
+        keys = txclient.ClientKeys(p, seed=args.fhe_seed)
+        keys.trans_key = keys.ctr_luts(key, seed=args.fhe_seed + 1) if args.size else keys.round_luts(key, seed=args.fhe_seed + 1)
     eng = txhip.Engine(p, device=dev_index)
     eng.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
-    if args.size:
-        eng.load_ctr_luts(keys.ctr_luts(key, seed=args.fhe_seed + 1))
-    else:
-        eng.load_round_luts(keys.round_luts(key, seed=args.fhe_seed + 1))
+    (eng.load_ctr_luts if args.size else eng.load_round_luts)(np.ascontiguousarray(keys.trans_key))
     words = eng.big
 
     def to_np(t):
@@ -145,7 +166,14 @@ def main():
     sync(); t["inner_product_s"] = time.perf_counter() - t0
 
     ok = True
-    if rank == 0:
+    if rank == 0 and args.io:
+        # what the two server stages write (host/stages.cpp): the result LWEs and the mini-workload's 16 LWEs
+        txclient.write_words(os.path.join(io_dir, "ciphertext_aes_download", "result.bin"), to_np(res))
+        txclient.write_words(os.path.join(io_dir, "ciphertexts_download", "result.bin"), to_np(ip if args.mini_workload == 1 else mx))
+    if rank == 0 and db is None:
+        print(json.dumps({"size": args.size, "values": n_values, "blocks": n_blocks, "ranks": world, "backend": args.backend,
+                          "checks": None, "blind_rotate_kernel": br_kernel, **{k: round(v, 4) for k, v in t.items()}}), flush=True)
+    elif rank == 0:
         vals = [int(v) for v in db]
         half = len(vals) // 2
         got = txclient.bits_to_u16(keys.decrypt_bits(to_np(res)))

@@ -37,7 +37,9 @@ def du(path):
     return total
 
 
-def run(size, root, seed=None, dataset_seed=None, fhe_seed=None, mini_workload=0):
+def run(size, root, seed=None, dataset_seed=None, fhe_seed=None, mini_workload=0, server_ranks=0, backend="nccl"):
+    """server_ranks > 0: the two server stages are replaced by ONE run of run_sharded.py --io over that many rank processes
+    (one per GPU; --backend gloo lets them share a card), which reads and writes the same files under io/<size>/"""
     import numpy as np
     import txclient
     name = NAMES[size]
@@ -88,6 +90,18 @@ def run(size, root, seed=None, dataset_seed=None, fhe_seed=None, mini_workload=0
         env["TX_SEED"] = str(fhe_seed)
     bandwidth = {}
     for step, stage in STAGES:
+        if server_ranks and stage == "server_encrypted_compute":
+            continue
+        if server_ranks and stage == "server_encrypted_aes_decryption":
+            for d in ("ciphertext_aes_download", "ciphertexts_download"):
+                os.makedirs(os.path.join(io, d), exist_ok=True)
+            subprocess.run([sys.executable, os.path.join(HERE, "run_sharded.py"), str(size), "--io", root, "--gpus", str(server_ranks),
+                            "--backend", backend, "--mini_workload", str(mini_workload)] + (["--force-dist"] if server_ranks == 1 else []),
+                           cwd=root, check=True, env=env)
+            log(step, "server_encrypted_aes_decryption + server_encrypted_compute (run_sharded.py, %d ranks)" % server_ranks)
+            bandwidth["Encrypted AES decryption result"] = du(os.path.join(io, "ciphertext_aes_download"))
+            bandwidth["Encrypted compute result"] = du(os.path.join(io, "ciphertexts_download"))
+            continue
         subprocess.run([os.path.join(BIN, stage), str(size)], cwd=root, check=True, env=env)
         log(step, stage)
         if stage == "client_encode_encrypt":
@@ -119,9 +133,13 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--fhe_seed", type=int, default=0)
     ap.add_argument("--mini_workload", type=int, default=0, choices=[0, 1])
+    ap.add_argument("--server_ranks", type=int, default=0,
+                    help="run the server side as this many rank processes of run_sharded.py --io instead of the two server stage "
+                         "executables (which shard across TX_DEVICES in-process)")
+    ap.add_argument("--backend", default="nccl", help="--server_ranks: torch.distributed backend (gloo: ranks may share a GPU)")
     a = ap.parse_args()
     ds = None
     if a.seed is not None:                                  # run_submission.py:50-54
         import numpy as np
         ds = int(np.random.default_rng(a.seed).integers(0, 0x7fffffff))
-    sys.exit(0 if run(a.size, a.root, None, ds, a.fhe_seed, a.mini_workload) else 1)
+    sys.exit(0 if run(a.size, a.root, None, ds, a.fhe_seed, a.mini_workload, a.server_ranks, a.backend) else 1)

@@ -111,3 +111,58 @@ def aes_ctr_crypt(key, iv, data):
     k = np.frombuffer(bytes(key), np.uint8).copy(); v = np.frombuffer(bytes(iv), np.uint8).copy()
     lib().txc_aes128_ctr_crypt(_p8(k), _p8(v), _p8(d), C.c_size_t(d.size), _p8(o))
     return bytes(o)
+
+
+# ---- the stage executables' own file format (host/stages.cpp): 16-byte header {magic "TXU64", word count} + little-endian u64 ----
+_MAGIC = 0x0000003436555854
+
+
+def read_words(path):
+    """the u64 words of a TXU64 file, memory-mapped read-only; the header's count must match the file size"""
+    size = os.path.getsize(path)
+    if size < 16:
+        raise ClientError("bad header in " + path)
+    hdr = np.fromfile(path, dtype="<u8", count=2)
+    if int(hdr[0]) != _MAGIC:
+        raise ClientError("bad header in " + path)
+    if (size - 16) % 8 or (size - 16) // 8 != int(hdr[1]):
+        raise ClientError("word count in the header of " + path + " does not match the file size")
+    if int(hdr[1]) == 0:
+        return np.zeros(0, np.uint64)
+    return np.memmap(path, dtype="<u8", mode="r", offset=16, shape=(int(hdr[1]),))
+
+
+def write_words(path, words):
+    words = np.ascontiguousarray(words, dtype="<u8").reshape(-1)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        np.array([_MAGIC, words.size], dtype="<u8").tofile(f)
+        words.tofile(f)
+
+
+class StageKeys:
+    """What a SERVER finds under io/<size>/ after the client stages ran (client_key_generation, client_encode_encrypt):
+    public_keys/{bsk,ksk,auto_keys,ss_key}.bin and ciphertexts_upload/trans_key.bin, checked against the parameter set.
+    The secret key is loaded only if it is there (a test harness on one machine; a real server never has it)."""
+
+    def __init__(self, p, io_dir):
+        L = lib()
+        self.p = p
+        pk = os.path.join(io_dir, "public_keys")
+        self.bsk, self.ksk = read_words(os.path.join(pk, "bsk.bin")), read_words(os.path.join(pk, "ksk.bin"))
+        self.auto, self.ss = read_words(os.path.join(pk, "auto_keys.bin")), read_words(os.path.join(pk, "ss_key.bin"))
+        want = (L.txc_bsk_words(C.byref(p)), L.txc_ksk_words(C.byref(p)), L.txc_auto_words(C.byref(p)), L.txc_ss_words(C.byref(p)))
+        if (self.bsk.size, self.ksk.size, self.auto.size, self.ss.size) != want:
+            raise ClientError("public_keys/*.bin do not match the AES_TIGHT parameter set")
+        self.trans_key = read_words(os.path.join(io_dir, "ciphertexts_upload", "trans_key.bin"))
+        sk = os.path.join(io_dir, "secret_keys", "glwe_sk.bin")
+        self.glwe_sk = np.array(read_words(sk)) if os.path.exists(sk) else None
+
+    def decrypt_bits(self, lwe):
+        if self.glwe_sk is None:
+            raise ClientError("no secret key under io/: a server cannot decrypt")
+        lwe = np.ascontiguousarray(lwe, np.uint64)
+        cnt = lwe.size // (self.p.k * self.p.N + 1)
+        bits = np.zeros(cnt, np.uint8)
+        lib().txc_decrypt_bits(C.byref(self.p), _p64(self.glwe_sk), _p64(lwe), C.c_size_t(cnt), _p8(bits))
+        return bits

@@ -22,19 +22,30 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """number of HIP devices a process started from here would see, counted in a short-lived CHILD: on ROCm
+    torch.cuda.device_count() may fall through to hipGetDeviceCount and initialise the HIP runtime in the caller, which a
+    launcher that is about to start GPU ranks must not have done.  -1 if the count could not be taken."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else -1
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return -1
+
+
 def launch_ranks(script, argv, n, backend="nccl", need_gpu=True, prepare=None, name=None):
     """Start the n ranks of `script argv` as fresh child processes of a parent that was started as a plain command (no RANK in
-    its environment) and return the exit status for the parent.  Nothing here touches the GPU -- importing torch and counting
-    devices does not initialise it -- and no process is replaced: the ranks are ordinary subprocesses (RANK / LOCAL_RANK /
+    its environment) and return the exit status for the parent.  Nothing here touches the GPU -- the devices are counted by a
+    child process (visible_gpus) -- and no process is replaced: the ranks are ordinary subprocesses (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in their environment), rank 0's output reaches stdout through the
     inherited descriptor, and the status is the first non-zero status of a rank (the others are then stopped, by PID).
     Fails fast, with one line, on a node that has fewer GPUs than ranks (nccl: one rank per GPU; gloo rehearsals may share).
     `prepare` runs once in the parent before the ranks start (building the in-tree libraries)."""
     name = name or os.path.basename(script)
     if need_gpu:
-        import torch
-        ndev = torch.cuda.device_count()
-        if ndev == 0:
+        ndev = visible_gpus()
+        if ndev <= 0:
             print(f"{name}: no HIP device on this node; there is no CPU fallback for the product path", file=sys.stderr)
             return 2
         if backend == "nccl" and ndev < n:

@@ -46,7 +46,7 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_max_u16_io", "tx_inner_product_u16_io", "tx_stage_circuit_bootstrap", "tx_timing_size",
            "tx_device_alloc", "tx_device_free", "tx_device_upload", "tx_device_download",
            "tx_transcipher_chunks", "tx_chunk_blocks", "tx_set_ctr_column_sharing", "tx_host_alloc", "tx_host_free",
-           "tx_device_count"]
+           "tx_device_count", "tx_host_register", "tx_host_unregister", "tx_reserve"]
 
 # the experiment build: the same sources with -DTXD_EXPERIMENTS (superseded kernels + TX_*_VARIANT knobs); tests and A/B tools only
 EXP_LIB_PATH = os.path.join(PKG_DIR, "libtfhe_mi355x_exp.so")
@@ -109,6 +109,9 @@ def lib(experiments=False):
         L.tx_host_alloc.argtypes = [C.c_size_t]
         L.tx_host_free.argtypes = [C.c_void_p]
         L.tx_device_count.argtypes = []
+        L.tx_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.tx_host_unregister.argtypes = [C.c_void_p]
+        L.tx_reserve.argtypes = [C.c_void_p, C.c_size_t]
         _LIBS[path] = L
         if not experiments:
             _LIB = L
@@ -248,6 +251,9 @@ class Engine:
                 del out
                 self.L.tx_host_free(C.c_void_p(hp))
         return res, seen, arrived
+
+    def reserve(self, n_blocks):
+        self._chk(self.L.tx_reserve(self.h, n_blocks))
 
     def set_ctr_column_sharing(self, enabled):
         self._chk(self.L.tx_set_ctr_column_sharing(self.h, 1 if enabled else 0))

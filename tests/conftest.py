@@ -10,8 +10,9 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "experiments: emulator runs of generators whose kernels are NOT in the library (measured, "
-                                       "not adopted: tools/asmgen/brgen2.py, trgen2.py); deselected unless -m experiments is given")
+    config.addinivalue_line("markers", "experiments: emulator runs of generators whose kernels are NOT in the product library (measured, "
+                                       "not adopted: tools/asmgen/brgen2.py, trgen2.py; lutgen.py's k_lut_eval4 lives in the experiment "
+                                       "build only); deselected unless -m experiments is given")
     # the in-tree shared libraries are build artefacts (git-ignored): (re)build them when they are
     # missing or older than their sources; hipcc cross-compiles without a GPU
     import __graft_entry__

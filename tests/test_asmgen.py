@@ -95,7 +95,8 @@ def test_generated_scheme_switch_equals_oracle_four_waves(oracle):
 
 @pytest.mark.experiments
 def test_generated_lut_tree_equals_oracle(oracle):
-    """tools/asmgen/lutgen.py (k_lut_eval4, selectable with TX_LUT_VARIANT=4): eight CMux steps in the emulator against a reference
+    """tools/asmgen/lutgen.py (k_lut_eval4: since round 5 only in the experiment build libtfhe_mi355x_exp.so, where TX_LUT_VARIANT=4
+    selects it; the product library does not contain it, so its emulator run rides with the experiments): eight CMux steps in the emulator against a reference
     built from the oracle's primitives on the whole accumulator, and against txo_lut_eval's four extracted LWEs"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_lut.py"), "8", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr

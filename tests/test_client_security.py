@@ -152,3 +152,36 @@ def test_eval_key_word_counts_are_exported_and_consistent():
     assert L.txc_auto_words(C.byref(p)) == 10 * 2 * 3 * K * N
     assert L.txc_ss_words(C.byref(p)) == 2 * 2 * K * K * N
     assert txhip.lib().tx_load_eval_keys.argtypes[2] is C.c_size_t
+
+
+def test_stage_file_format_round_trip_and_checks(tmp_path):
+    """the TXU64 format of the stage files (host/stages.cpp) as python/txclient.py reads and writes it: round trip, a
+    truncated file and a foreign file are refused; StageKeys (what a server finds under io/<size>/) checks the key
+    lengths against the parameter set and has no secret key unless the client left one on the same machine"""
+    import txclient
+    import txhip
+    w = np.arange(1000, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    f = str(tmp_path / "a" / "w.bin")
+    txclient.write_words(f, w)
+    assert os.path.getsize(f) == 16 + 8 * 1000
+    assert np.array_equal(np.array(txclient.read_words(f)), w)
+    raw = open(f, "rb").read()
+    open(f, "wb").write(raw[:-8])
+    with pytest.raises(txclient.ClientError, match="does not match the file size"):
+        txclient.read_words(f)
+    open(f, "wb").write(b"NOTTXU64" + raw[8:])
+    with pytest.raises(txclient.ClientError, match="bad header"):
+        txclient.read_words(f)
+    # a stage executable reads what python wrote and refuses it for its length, not for its format
+    p = txhip.aes_tight()
+    io = tmp_path / "io" / "toy"
+    for name in ("bsk", "ksk", "auto_keys", "ss_key"):
+        txclient.write_words(str(io / "public_keys" / (name + ".bin")), w)
+    txclient.write_words(str(io / "ciphertexts_upload" / "trans_key.bin"), w)
+    with pytest.raises(txclient.ClientError, match="do not match the AES_TIGHT parameter set"):
+        txclient.StageKeys(p, str(io))
+    os.makedirs(tmp_path / "datasets" / "toy")
+    (tmp_path / "datasets" / "toy" / "db.hex").write_text("00" * 16)
+    exe = os.path.join(ROOT, "temp-fhe-transciphering_amd", "bin", "server_encrypted_aes_decryption")
+    r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "do not match the AES_TIGHT parameter set" in r.stderr

@@ -223,7 +223,9 @@ class Gen:
     def gload(self, op, d, voff, sbase, offset=0):
         if "K" in ABL and op == "global_load_dwordx4": return          # timing experiment: results are garbage
         self.e(op, d, voff, sbase, offset=offset)
-    def gstore(self, op, voff, src, sbase, offset=0): self.e(op, voff, src, sbase, offset=offset)
+    def gstore(self, op, voff, src, sbase, offset=0, cache=None):
+        if cache: self.e(op, voff, src, sbase, offset=offset, cache=cache)
+        else: self.e(op, voff, src, sbase, offset=offset)
 
     def setprio(self, phase):
         hi = 1 if phase in self.prio else 0

@@ -584,8 +584,8 @@ class Emu:
         self.vmq.append(([], apply))
 
     def op_global_store_dword(self, voff, src, sbase, offset=0, cache=None): self._gstore(voff, src, sbase, offset, 1)
-    def op_global_store_dwordx2(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 2)
-    def op_global_store_dwordx4(self, voff, src, sbase, offset=0): self._gstore(voff, src, sbase, offset, 4)
+    def op_global_store_dwordx2(self, voff, src, sbase, offset=0, cache=None): self._gstore(voff, src, sbase, offset, 2)
+    def op_global_store_dwordx4(self, voff, src, sbase, offset=0, cache=None): self._gstore(voff, src, sbase, offset, 4)     # cache: "nt" etc. (no effect on values)
 
 
 def run_group(emus, prog):

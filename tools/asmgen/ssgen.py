@@ -83,6 +83,12 @@ class SsGen(TraceGen):
         e("v_cvt_f64_u32", w, w.lo())
         e("v_fma_f64", w, tB, -TS.C_M2P32, w)
 
+    # SS_NT=1 (default since round 5): the Fourier GGSW rows leave with the non-temporal hint.  A launch writes 3.9 GB of them
+    # (72 KiB per unit) through the same L2 that serves the 3.2 MB of automorphism / scheme-switching keys every wave streams:
+    # counters of the round-4 form showed 2.2 GB of fabric reads per launch for 0.2 GB of input -- the keys, evicted by the
+    # output stream and re-fetched.  The rows are read next by another kernel from HBM either way (4.2 GB > any cache).
+    NT = os.environ.get("SS_NT", "1") != "0"
+
     def scale_store(self, polys, row):
         """three transforms -> x 2^-9 -> OUT[row][c][r][lane]"""
         e = self.e
@@ -93,7 +99,7 @@ class SsGen(TraceGen):
                 q = polys[c][r]
                 e("v_mul_f64", qre(q), qre(q), TS.C_2M32)          # this loop keeps 2^-9 in that register pair (prologue)
                 e("v_mul_f64", qim(q), qim(q), TS.C_2M32)
-                self.gstore("global_store_dwordx4", L16 if r < 4 else OFF1, q, TS.KP_, offset=(r & 3) * 1024)
+                self.gstore("global_store_dwordx4", L16 if r < 4 else OFF1, q, TS.KP_, offset=(r & 3) * 1024, cache="nt" if self.NT else None)
 
     # ------------------------------------------------------------------ the kernel body
     def prologue(self):

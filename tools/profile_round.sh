@@ -11,12 +11,12 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-equal-work-legs > $out/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-equal-work-legs --no-stage-times > $out/bench_profiled.log 2>&1
 grep "^{" $out/bench_profiled.log | tail -1 > $out/bench_line_profiled.json
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o fetch --output-format csv -- python3 $R/tools/br_only.py 768 8192 1 > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o write --output-format csv -- python3 $R/tools/br_only.py 768 8192 1 > $out/write.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch_bench -o fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs > $out/fetch_bench.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $out/write_bench -o write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs > $out/write_bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch_bench -o fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs --no-stage-times > $out/fetch_bench.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/write_bench -o write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs --no-stage-times > $out/write_bench.log 2>&1
 python3 - <<PY
 import csv, glob
 for name in ("fetch_bench", "write_bench"):

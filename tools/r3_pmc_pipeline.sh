@@ -4,6 +4,6 @@ set -e
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 for pat in "$@"; do
-  bash $R/tools/pmc_kernel.sh gpurun_out/${tag}_pmc_$pat $pat bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs > $R/gpurun_out/${tag}_pmc_$pat.txt 2>&1
+  bash $R/tools/pmc_kernel.sh gpurun_out/${tag}_pmc_$pat $pat bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-equal-work-legs --no-stage-times > $R/gpurun_out/${tag}_pmc_$pat.txt 2>&1
   cat $R/gpurun_out/${tag}_pmc_$pat.txt
 done
