@@ -1,7 +1,7 @@
 """exploratory: per-kernel-family average launch time of one medium CTR transcipher with random keys (timing is
 data-independent); TX_LIB selects an ablation build, e.g. -DTXD_ABL_NOKEY"""
 import sys, os
-sys.path.insert(0, "temp-fhe-transciphering_amd/python")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "temp-fhe-transciphering_amd", "python"))
 import numpy as np, txhip, txclient, ctypes as C
 if os.environ.get('TX_LIB'): txhip.LIB_PATH = os.environ['TX_LIB']
 p = txhip.aes_tight(n=768)
