@@ -54,7 +54,7 @@ def test_cooperative_loop_equals_oracle_three_waves(oracle):
 def test_paired_loops_equal_oracle_two_waves(oracle):
     """tools/asmgen/brgen2.py (two waves per unit, A = the mask polynomials and columns 0, 1, B = the body and column 2; two
     different programs; an experiment that is NOT in the library -- faster than the one-wave kernel standalone, slower under
-    the pipeline's sustained load, DESIGN.md section 11 -- kept runnable): two emulated waves sharing the LDS image and
+    the pipeline's sustained load, DESIGN_HISTORY.md section 11 -- kept runnable): two emulated waves sharing the LDS image and
     meeting at both barriers of every step, in both scheduling orders, against the oracle-built reference; without the
     barriers it must NOT match"""
     exe = os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate2.py")
@@ -68,7 +68,7 @@ def test_paired_loops_equal_oracle_two_waves(oracle):
 @pytest.mark.experiments
 def test_cooperative_trace_experiment_equals_oracle_two_waves(oracle):
     """tools/asmgen/trgen2.py (two waves per unit: A the low-split pass, B the high-split pass, mask polynomials in
-    registers; an experiment that is NOT in the library -- it measured slower than the one-wave loop, DESIGN.md section 11 --
+    registers; an experiment that is NOT in the library -- it measured slower than the one-wave loop, DESIGN_HISTORY.md section 11 --
     kept runnable): two emulated waves in both scheduling orders against txo_trace() with real keys, ten steps"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asmgen_emu_trace2.py"), "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr

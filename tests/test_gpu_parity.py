@@ -302,7 +302,7 @@ def test_noise_margins_of_the_medium_instance(rig768):
         measured 2^58.6 .. 2^59.1 over seeds) and standard deviation < 2^57.5 (measured 2^56.9);
     (2) over 8192 state LWEs after 3 bootstrapped ECB rounds (incl. the linear layer: the noisiest point of the
         schedule), key-switched and mod-switched as the blind rotation sees them: rotation error |e| <= 320 of a
-        512-unit margin, standard deviation < 62 units (measured 53-55; DESIGN.md section 5: 9.6 sigma).
+        512-unit margin, standard deviation < 62 units (measured 53-55; DESIGN_HISTORY.md section 5: 9.6 sigma).
     The reference ships the same measurements as helpers (cbs_lib/src/aes_he.rs:916-943, utils.rs:173-237)."""
     r = rig768
     O = r.O
