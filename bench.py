@@ -198,7 +198,7 @@ def parse_args(argv=None):
                          "result LWEs where they lie in HBM (tx_max_u16_io / tx_inner_product_u16_io, device in, device out), "
                          "verify both against the cleartext and report their seconds beside `value`")
     ap.add_argument("--no-stage-times", action="store_true",
-                    help="skip the run of the harness's stage executables that follows the timed region (stage_s: the wall time of "
+                    help="skip the run of the harness's stage executables in front of the timed region (stage_s: the wall time of "
                          "server_encrypted_aes_decryption / server_encrypted_compute as the harness clocks them, harness/utils.py:85-109)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -306,6 +306,12 @@ def main(argv=None):
         import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    # ---- the harness's clock, taken FIRST on rank 0 (this process holds no device memory yet; with N > 1 the other ranks wait
+    # in the rendezvous with idle GPUs): one medium instance through the ten stage executables, the two server stages sharded
+    # in-process over the N devices of the run (TX_DEVICES)
+    stage_s = None
+    if rank == 0 and not args.no_stage_times and args.n == 768:
+        stage_s = stage_times(world, args.seed)
     if args.backend == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs on this node, it has {torch.cuda.device_count()}")
     # one rank per GPU; a rehearsal with more ranks than GPUs (gloo only) wraps around
@@ -549,8 +555,7 @@ def main(argv=None):
              "traffic": (ke[k].get("bytes_per_launch") if k in ke else None),
              "launches_per_step": (ke[k].get("launches_per_step") if k in ke else None),
              "source": (ke[k].get("source") if k in ke else None)} for stage, k, key in fam]
-        if not args.no_stage_times and not args.dry_run and args.n == 768:
-            line["stage_s"] = stage_times(world, args.seed)
+        line["stage_s"] = stage_s
         if not args.no_cpu_baseline and world == 1:
             # the GPU box gives one GPU's job a share of 16 host cores; never more threads than that
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -227,8 +227,12 @@ class Engine:
             ivb = np.frombuffer(bytes(iv), np.uint8).copy()
             ivp = _p8(ivb)
         nbytes = nb * 128 * self.big * 8
-        hp = None
-        if pinned:
+        hp, reg = None, None
+        if pinned == "register":          # the caller's own memory, page-locked in place (tx_host_register)
+            out = np.empty(nb * 128 * self.big, np.uint64)
+            self._chk(self.L.tx_host_register(out.ctypes.data_as(C.c_void_p), nbytes))
+            reg = out.ctypes.data
+        elif pinned:
             hp = self.L.tx_host_alloc(nbytes)
             if not hp:
                 raise TxError(self.L.tx_last_error().decode())
@@ -247,6 +251,8 @@ class Engine:
             self._chk(self.L.tx_transcipher_chunks(self.h, _p8(ct), nb, ivp, out.ctypes.data_as(C.c_void_p), 0, cb, None))
             res = out.reshape(nb * 128, self.big).copy()
         finally:
+            if reg:
+                self.L.tx_host_unregister(C.c_void_p(reg))
             if hp:
                 del out
                 self.L.tx_host_free(C.c_void_p(hp))

@@ -510,6 +510,29 @@ def test_stage_executables_shard_across_devices_in_process(size, devices, tmp_pa
             shutil.rmtree(tmp_path / f"one{mw}"); shutil.rmtree(tmp_path / f"many{mw}")
 
 
+def test_sharded_runner_in_server_mode_honours_the_io_contract(tmp_path):
+    """run_sharded.py --io is the multi-PROCESS server behind the harness's files -- it reads the
+    client stages' public_keys/*.bin and trans_key.bin (no key generation of its own) and writes the two result.bin files the
+    server stages write.  `run_submission.py --server_ranks 2 --backend gloo` (two ranks sharing the card) verifies like any
+    other run, and the AES result ciphertexts equal those of the stage executables byte for byte (same keys, same blocks)"""
+    import subprocess
+    import sys as _sys
+    import filecmp
+    root = os.path.dirname(HERE)
+    rs = os.path.join(root, "temp-fhe-transciphering_amd", "python", "run_submission.py")
+    out = {}
+    for tag, extra in (("stages", []), ("ranks", ["--server_ranks", "2", "--backend", "gloo"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([_sys.executable, rs, "1", "--root", str(d), "--seed", "123", "--fhe_seed", "99", "--mini_workload", "1"] + extra,
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, TX_DEVICES="0", MASTER_ADDR="127.0.0.1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "AES decryption: PASS; inner product: PASS" in r.stdout
+        out[tag] = d / "io" / "small"
+    assert filecmp.cmp(out["stages"] / "ciphertext_aes_download" / "result.bin", out["ranks"] / "ciphertext_aes_download" / "result.bin", shallow=False)
+    assert filecmp.cmp(out["stages"] / "result.txt", out["ranks"] / "result.txt", shallow=False)
+
+
 def test_stage_rejects_a_bad_device_list(tmp_path):
     """a malformed or out-of-range TX_DEVICES is exit status 1 with a message (the harness aborts: check=True), never a crash"""
     import subprocess
@@ -532,12 +555,22 @@ def test_host_output_is_pipelined_chunk_by_chunk(rig256):
     rng = np.random.default_rng(78)
     ct = rng.integers(0, 256, 16 * 300, dtype=np.uint8).tobytes()
     want = r.eng.transcipher(ct, iv=AES_IV)
-    for pinned in (True, False):
+    for pinned in (True, False, "register"):
         got, seen, arrived = r.eng.transcipher_chunks(ct, iv=AES_IV, pinned=pinned)
         assert seen == [(0, 128), (128, 128), (256, 44)] and all(arrived), (pinned, seen, arrived)
         assert np.array_equal(got, want)
     one, seen, arrived = r.eng.transcipher_chunks(ct[:16 * 5], iv=AES_IV)
     assert seen == [(0, 5)] and all(arrived) and np.array_equal(one, want[:5 * 128])
+    # tx_reserve: the workspace announced before the keys arrive is allocated underneath their transforms; same results
+    import txhip
+    e = txhip.Engine(txhip.aes_tight(n=r.p.n), 0)
+    e.reserve(300)
+    e.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
+    e.load_ctr_luts(r.ctr_luts)
+    assert np.array_equal(e.transcipher(ct[:16 * 130], iv=AES_IV), want[:130 * 128])
+    e.reserve(4)                                    # smaller than what is there: nothing to do
+    assert np.array_equal(e.transcipher(ct[:16 * 3], iv=AES_IV), want[:3 * 128])
+    e.close()
 
 
 def test_two_contexts_driven_from_two_threads(rig256):
