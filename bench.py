@@ -436,6 +436,36 @@ def main(argv=None):
         eng2.close()
         del out2
 
+    # ---- host-output leg (one GPU): the same instance with the result LWEs delivered to HOST memory -- what a caller without
+    # device pointers gets (the stage executables): tx_transcipher_chunks into page-locked memory, the 134 MB travelling on the
+    # copy stream.  PCIe-inclusive, reported beside `value`, never as `value`.
+    value_host = None
+    if world == 1 and not args.no_equal_work_legs:
+        import ctypes as C
+        L = txhip.lib()
+        nbytes = n_blocks * 128 * words * 8
+        hp = L.tx_host_alloc(nbytes)
+        if hp:
+            ctb = np.frombuffer(bytes(ct), np.uint8).copy()
+            ivb = np.frombuffer(bytes(iv), np.uint8).copy() if iv is not None else None
+            cb = txhip.CHUNK_FN(lambda u, a, b: None)
+
+            def host_step():
+                rc = L.tx_transcipher_chunks(eng.h, ctb.ctypes.data_as(txhip.u8p), n_blocks,
+                                             ivb.ctypes.data_as(txhip.u8p) if ivb is not None else None, C.c_void_p(hp), 0, cb, None)
+                if rc:
+                    raise SystemExit("bench.py: host-output leg failed: " + L.tx_last_error().decode())
+            host_step()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                host_step()
+            value_host = n_blocks * 2 / (time.perf_counter() - t1)
+            got = np.ctypeslib.as_array(C.cast(hp, txhip.u64p), shape=(n_blocks * 128 * words,))
+            if not np.array_equal(txclient.bits_to_u16(keys.decrypt_bits(got)), db):
+                raise SystemExit("bench.py: the host-output leg's result does not decrypt to the plaintext; no number reported")
+            del got
+            L.tx_host_free(C.c_void_p(hp))
+
     # ---- the two post-transcipher mini-workloads on the device-resident result (config 5 of BASELINE.json at --blocks 512)
     mini = None
     if args.with_mini_workloads:
@@ -501,6 +531,7 @@ def main(argv=None):
                        "blocks": n_blocks, "blocks_per_gpu": m_local, "parallelism": f"block-sharded x{world}, one gather",
                        "backend": (args.backend if dist is not None else None)},
             "value_without_sharing": value_unshared, "value_ecb_schedule": value_ecb,
+            "value_host_result": value_host,       # PCIe-inclusive: result LWEs delivered to page-locked host memory (never `value`)
             "roofline": {"bound": "fp64_valu", "bound_note": "what binds is the FP64 vector pipe (fp64_valu / vector_pipe_busy_pmc below); "
                                        "achieved / peak / frac are the HBM figure the contract asks for: algorithmic bytes of the dominant "
                                        "kernel per second against 8 TB/s",
