@@ -116,6 +116,19 @@ size_t tx_chunk_blocks(void);
  * Same ciphertexts either way; the switch exists for equal-work measurements (bench.py's value_without_sharing). */
 int tx_set_ctr_column_sharing(tx_ctx *c, int enabled);
 
+/* Which way a TOP-LEVEL tie of the signed gadget decomposition goes (digit = B/2 exactly at level 1, no bits above it to decide).
+ * tfhe-rs 0.5.4's SignedDecomposer -- what the reference calls at cbs_lib/src/fourier_glwe_keyswitch.rs:264,282 and
+ * pbs.rs:153-159 -- always takes +B/2.  For the circuit-bootstrapping gadget (B = 4: one coefficient in four is a tie) that gives
+ * the top digit a mean of +B/8, which multiplies the structured noise of the scheme-switched GGSW rows into a coherent term and
+ * costs the bootstrap 3.7 sigma of margin.  TX_TIE_BALANCED (the default) sends the tie to +B/2 on even and
+ * to -B/2 on odd coefficient indices: the same value mod 2^64, zero mean.  TX_TIE_TFHE_RS makes every decomposition of the path
+ * (key switch, blind rotation, trace, scheme switch, LUT tree, mini-workloads) follow tfhe-rs digit for digit, so that the product
+ * can be put beside a build of the reference at the ciphertext level; its outputs equal the oracle's under
+ * txo_set_top_digit_rule(1) bit for bit.  Takes effect with the next call on the context. */
+#define TX_TIE_BALANCED 0
+#define TX_TIE_TFHE_RS  1
+int tx_set_decomposer_tie_rule(tx_ctx *c, int rule);
+
 /* Page-locked host memory, usable with every context of the process (hipHostMalloc, portable): result buffers allocated here
  * are written by DMA at link speed instead of through the runtime's staging copies.  No context needed; NULL on failure. */
 void *tx_host_alloc(size_t bytes);

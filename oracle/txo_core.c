@@ -137,6 +137,12 @@ static void poly_mul_small_acc(uint32_t N, const uint64_t *a, const int64_t *s, 
  * sigma; one wrong bit per ~10^6 bootstraps with the tfhe rule).  Here the tie goes to +B/2 on even and
  * -B/2 on odd coefficient indices (`odd`): the same value mod 2^64, zero mean.  Compile with
  * -DTXO_TFHE_TOP_DIGIT to get tfhe-rs' rule back. */
+/* run-time form of -DTXO_TFHE_TOP_DIGIT: 1 = tfhe-rs' rule (a top-level tie always goes to +B/2), 0 = balanced (default).
+ * Process-wide (the oracle is test infrastructure; tests switch it around the calls they compare). */
+static int g_tfhe_top_digit = 0;
+void txo_set_top_digit_rule(int tfhe_rs) { g_tfhe_top_digit = tfhe_rs ? 1 : 0; }
+int txo_get_top_digit_rule(void) { return g_tfhe_top_digit; }
+
 void txo_decompose_idx(uint64_t x, uint32_t base_log, uint32_t level, uint32_t odd, int64_t *digits)
 {
     uint32_t nonrep = 64 - base_log * level;
@@ -152,6 +158,7 @@ void txo_decompose_idx(uint64_t x, uint32_t base_log, uint32_t level, uint32_t o
 #ifdef TXO_TFHE_TOP_DIGIT
     odd = 0;
 #endif
+    if (g_tfhe_top_digit) odd = 0;
     uint64_t tie = (uint64_t)(odd & 1) << (base_log - 1);
     for (uint32_t i = 0; i < level; i++) {
         uint64_t res = state & mask;

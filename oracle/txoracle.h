@@ -169,6 +169,11 @@ void txo_decompose(uint64_t x, uint32_t base_log, uint32_t level, int64_t *digit
 /* same for the coefficient of index parity `odd`: the top-level tie B/2 goes to -B/2 on odd indices
  * (the one deviation from tfhe-rs, see txo_core.c) */
 void txo_decompose_idx(uint64_t x, uint32_t base_log, uint32_t level, uint32_t odd, int64_t *digits);
+/* 1: every decomposition follows tfhe-rs 0.5.4's SignedDecomposer exactly (a tie at the top level goes to +B/2 on every
+ * coefficient: cbs_lib/src/fourier_glwe_keyswitch.rs:264,282, pbs.rs:153-159); 0 (default): the balanced rule above.
+ * The product's counterpart is tx_set_decomposer_tie_rule (include/tfhe_mi355x.h). */
+void txo_set_top_digit_rule(int tfhe_rs);
+int txo_get_top_digit_rule(void);
 uint32_t txo_modswitch(uint64_t x, uint32_t log2N, uint32_t log_lut_count);
 /* cleartext AES-128 (aes_manager.rs:131-433) */
 void txo_aes128_expand(const uint8_t key[16], uint8_t rk[11][16]);

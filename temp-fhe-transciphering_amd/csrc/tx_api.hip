@@ -56,6 +56,7 @@ struct tx_ctx {
     int br_variant = -1;                    // -1: by launch size (run_br); TX_BR_VARIANT=0|3|4|5 forces a kernel
     int br5_wgs = 0;                        // 0: one workgroup per CU; TX_BR5_WGS caps the persistent grid (experiments)
     int trss_wgs_per_cu = 1;                // TX_TRSS_WGS_PER_CU (experiments)
+    int tie_on = 1;                         // 1: balanced top-level decomposition tie (default); 0: tfhe-rs' SignedDecomposer rule (tx_set_decomposer_tie_rule)
     int ctr_share = 1;                      // TX_CTR_SHARE=0: the CTR schedule bootstraps every column of its second round, shared or not
     const char *last_br_kernel = "";        // blind-rotation kernel that took most units of the last call (tx_last_blind_rotate_kernel)
     struct BrUse { const char *kernel; uint64_t units; uint32_t launches; };
@@ -542,7 +543,7 @@ static void run_ks(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *out)
 {
     ev_begin(c, F_KS);
     hipLaunchKernelGGL(k_lwe_keyswitch, dim3(grid_for(count)), dim3(256), 0, c->stream, in, out, (int)count, (int)c->p.n,
-                       c->ksk_f, c->tw256);
+                       c->ksk_f, c->tw256, c->tie_on);
     ev_end(c);
 }
 // which kernel(s) a blind rotation of `count` units runs on a chip of `cus` CUs (host logic, no GPU; the rule is explained
@@ -583,7 +584,7 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
     if (variant == 7) {
         ev_begin(c, F_BR, "k_blind_rotate7", count);
         hipLaunchKernelGGL(k_blind_rotate7, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
-                           c->bsk_f, c->tw, c->fair_tab);
+                           c->bsk_f, c->tw, c->fair_tab, c->tie_on);
     } else if (variant == 6) {
         // launch number 0 = no arbitration: with at most one workgroup per CU there is nobody to be fair to
         uint32_t ep = count <= (size_t)c->num_cus ? 0u : (++c->br6_epoch & 0x7FFFu);          // 15 bits above the 16-bit step count of a table word
@@ -593,16 +594,16 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
         }
         ev_begin(c, F_BR, "k_blind_rotate6", count);
         hipLaunchKernelGGL(k_blind_rotate6, dim3(count), dim3(192), LDS_BYTES_BR6, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw,
-                           c->fair_tab, ep << 16);
+                           c->fair_tab, ep << 16, c->tie_on);
     } else if (variant == 5) {
         size_t wgs = std::min<size_t>(count, (size_t)c->num_cus);     // persistent, one per CU; units are dealt wave-major
         if (c->br5_wgs > 0) wgs = std::min<size_t>(wgs, (size_t)c->br5_wgs);                                       // experiments only
         ev_begin(c, F_BR, "k_blind_rotate5", count);
-        hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+        hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw, c->tie_on);
 #ifdef TXD_EXPERIMENTS
     } else if (variant == 4) {
         ev_begin(c, F_BR, "k_blind_rotate4", count);
-        hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw);
+        hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw, c->tie_on);
 #ifdef TXD_WITH_BR3
     } else if (variant == 3) {
         ev_begin(c, F_BR, "k_blind_rotate3", count);
@@ -656,7 +657,7 @@ static void run_extract_trace(tx_ctx *c, const uint64_t *acc, size_t count, uint
     else
 #endif
         hipLaunchKernelGGL(k_extract_trace4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, acc, glev,
-                           (int)count, c->auto_f, c->auto_split_stride, c->tw);
+                           (int)count, c->auto_f, c->auto_split_stride, c->tw, c->tie_on);
     ev_end(c);
 }
 static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
@@ -669,7 +670,7 @@ static void run_ss(tx_ctx *c, const uint64_t *glev, size_t count, cplx *ggsw_f)
     else
 #endif
         hipLaunchKernelGGL(k_scheme_switch4, dim3(grid_for(count * CBS_L)), dim3(256), LDS_BYTES_TR4, c->stream, glev, ggsw_f,
-                           (int)(count * CBS_L), c->ss_f, c->tw);
+                           (int)(count * CBS_L), c->ss_f, c->tw, c->tie_on);
     ev_end(c);
 }
 static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t *lut_set, size_t lut_stride, int nlut,
@@ -684,7 +685,7 @@ static void run_lut(tx_ctx *c, const cplx *ggsw_f, size_t nbytes, const uint64_t
     else
 #endif
         hipLaunchKernelGGL(k_lut_eval, grid, dim3(256), LDS_BYTES, c->stream, ggsw_f, lut_set,
-                           lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos);
+                           lut_stride, (size_t)2 * GL, out, (int)nbytes, nlut, c->tw, pos, c->tie_on);
     ev_end(c);
 }
 // KS + CBS of `count` big LWEs into Fourier GGSWs
@@ -696,7 +697,7 @@ static int run_cbs(tx_ctx *c, const uint64_t *lwe_big, size_t count, cplx *ggsw_
         ev_begin(c, F_TRACE);                                // (reported under ms_trace; ms_scheme_switch stays 0)
         const int wgs = std::min(grid_for(count * CBS_L), c->num_cus * c->trss_wgs_per_cu);
         hipLaunchKernelGGL(k_trace_scheme_switch4, dim3(wgs), dim3(256), LDS_BYTES_TR4, c->stream, c->acc, ggsw_f,
-                           (int)count, c->auto_f, c->auto_split_stride, c->ss_f, c->tw);
+                           (int)count, c->auto_f, c->auto_split_stride, c->ss_f, c->tw, c->tie_on);
         ev_end(c);
         return 0;
     }
@@ -944,6 +945,17 @@ extern "C" int tx_set_ctr_column_sharing(tx_ctx *c, int enabled)
     return 0;
 }
 
+extern "C" int tx_set_decomposer_tie_rule(tx_ctx *c, int rule)
+{
+    if (!c) return fail("tx_set_decomposer_tie_rule: null context");
+    if (rule != TX_TIE_BALANCED && rule != TX_TIE_TFHE_RS) return fail("tx_set_decomposer_tie_rule: rule must be TX_TIE_BALANCED (0) or TX_TIE_TFHE_RS (1)");
+#ifdef TXD_EXPERIMENTS
+    if (rule == TX_TIE_TFHE_RS) return fail("tx_set_decomposer_tie_rule: the experiment build's superseded kernels have the balanced rule only");
+#endif
+    c->tie_on = rule == TX_TIE_BALANCED ? 1 : 0;
+    return 0;
+}
+
 extern "C" int tx_transcipher_partial(tx_ctx *c, const uint8_t *ct_blocks, size_t n_blocks, int rounds_done, uint64_t *out_state)
 {
     if (rounds_done < 0 || rounds_done > 9) return fail("tx_transcipher_partial: rounds_done out of range");
@@ -1111,13 +1123,13 @@ static int max_impl(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64
                 ev_begin(c, F_LUT);                         // (no early return between ev_begin and ev_end)
                 hipMemcpyAsync(M0.p, E.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
                 hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M0.p,
-                                   (const uint64_t *)B.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? B : e
+                                   (const uint64_t *)B.p, c->ggsw_f, sb, (int)units, c->tw, c->tie_on);     // b_i ? B : e
                 hipMemcpyAsync(M1.p, A.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
                 hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)M1.p,
-                                   (const uint64_t *)E.p, c->ggsw_f, sb, (int)units, c->tw);     // b_i ? e : A
+                                   (const uint64_t *)E.p, c->ggsw_f, sb, (int)units, c->tw, c->tie_on);     // b_i ? e : A
                 hipMemcpyAsync(E.p, M0.p, units * GL * 8, hipMemcpyDeviceToDevice, c->stream);
                 hipLaunchKernelGGL(k_cmux, dim3(grid_for(units)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)E.p,
-                                   (const uint64_t *)M1.p, c->ggsw_f, sa, (int)units, c->tw);    // a_i ? m1 : m0
+                                   (const uint64_t *)M1.p, c->ggsw_f, sa, (int)units, c->tw, c->tie_on);    // a_i ? m1 : m0
                 ev_end(c);
             }
             hipLaunchKernelGGL(k_extract0, dim3(ew_grid(units * BIG)), dim3(256), 0, c->stream, (const uint64_t *)E.p,
@@ -1290,7 +1302,7 @@ static int ip_impl(tx_ctx *c, const uint64_t *lwe_bits, size_t n_values, uint64_
                                (const int *)dc1.p, (const int *)df1.p, (uint64_t *)g1.p, nj);
             ev_begin(c, F_LUT);
             hipLaunchKernelGGL(k_cmux, dim3(grid_for(nj)), dim3(256), LDS_BYTES, c->stream, (uint64_t *)g0.p, (const uint64_t *)g1.p,
-                               c->ggsw_f, (const int *)dsel.p, nj, c->tw);
+                               c->ggsw_f, (const int *)dsel.p, nj, c->tw, c->tie_on);
             ev_end(c);
             hipLaunchKernelGGL(k_extract0_scatter, dim3(ew_grid((size_t)nj * BIG)), dim3(256), 0, c->stream, (const uint64_t *)g0.p,
                                (const int *)dout.p, (uint64_t *)pool.p, nj);

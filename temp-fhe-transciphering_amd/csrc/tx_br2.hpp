@@ -281,7 +281,7 @@ void k_blind_rotate3(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 // ------------------------------------------------------------------------------------------
 #ifdef TXD_EXPERIMENTS   // superseded / reference form: only in libtfhe_mi355x_exp.so (tests, A/B timing)
 __global__ __launch_bounds__(256, 2)
-void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
@@ -318,7 +318,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br_asm_stamps.inc"
         :
-        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(dbg)
+        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(tie_on), "s"(dbg)
         :
 #include "tx_br_asm_clobbers.inc"
     );
@@ -327,7 +327,7 @@ void k_blind_rotate4(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br_asm.inc"
         :
-        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr)
+        : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(tie_on)
         :
 #include "tx_br_asm_clobbers.inc"
     );
@@ -358,7 +358,7 @@ constexpr size_t LDS_BYTES_BR5 = BR3_TW_CPLX * sizeof(cplx) + BR5_WAVES * BR3_WA
 // to wave 1, ...; waves 0-3 sit on the four SIMDs, waves 4-7 double them up).  The step counters keep counting
 // across units.  A wave leaves when its share is done (it then reads as "finished" to its partner).
 __global__ __launch_bounds__(512, 2)
-void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g)
+void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
@@ -405,7 +405,7 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
         asm volatile(
 #include "tx_br_asm_fair_stamps.inc"
             :
-            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps), "s"(dbg)
+            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps), "s"(tie_on), "s"(dbg)
             :
 #include "tx_br_asm_clobbers.inc"
         );
@@ -413,7 +413,7 @@ void k_blind_rotate5(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
         asm volatile(
 #include "tx_br_asm_fair.inc"
             :
-            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps)
+            : "s"(ct), "s"(bsk_f), "s"(out), "s"(n), "s"(tile_addr), "s"(prog_a), "s"(prog_b), "s"(done_steps), "s"(tie_on)
             :
 #include "tx_br_asm_clobbers.inc"
         );
@@ -454,7 +454,7 @@ static_assert(4 * LDS_BYTES_BR6 <= 160 * 1024, "four workgroups per CU");
 
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g,
-                     uint32_t *fair_tab, uint32_t epoch_shl16)
+                     uint32_t *fair_tab, uint32_t epoch_shl16, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];         // (no static __shared__ here: the generated loop reads the twiddles at LDS address 0)
     uint32_t &fair_slot = *reinterpret_cast<uint32_t *>(lds + LDS_BYTES_BR6 - 16);
@@ -512,7 +512,7 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm_stamps.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16), "s"(dbg)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16), "s"(tie_on), "s"(dbg)
         :
 #include "tx_br3_asm_clobbers.inc"
     );
@@ -521,7 +521,7 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_entry), "s"(fair_off), "s"(epoch_shl16), "s"(tie_on)
         :
 #include "tx_br3_asm_clobbers.inc"
     );
@@ -549,7 +549,7 @@ static_assert(BR6_PF_ROWS == 0, "k_blind_rotate7 passes the unit's own tiles as 
 constexpr size_t LDS_BYTES_BR7 = BR3_TW_CPLX * sizeof(cplx) + BR7_UNITS * BR6_WAVES * BR3_TILE_BYTES + 1024;
 
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, uint32_t *fair_tab)
+void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, uint32_t *fair_tab, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
@@ -594,7 +594,7 @@ void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm_stamps.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch), "s"(dbg)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch), "s"(tie_on), "s"(dbg)
         :
 #include "tx_br3_asm_clobbers.inc"
     );
@@ -603,7 +603,7 @@ void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3_asm.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(fair_tab), "s"(fair_off), "s"(no_epoch), "s"(tie_on)
         :
 #include "tx_br3_asm_clobbers.inc"
     );
@@ -642,7 +642,7 @@ __device__ __forceinline__ void tr4_extract_to_lds(const uint64_t *a, int lvl, u
     for (int m = 0; m < 16; m++) gl[2 * N + lane + 64 * m] = (lane + 64 * m == 0) ? b0 : 0;
 }
 // a7: the generated trace loop on the GLWE behind `tile` (tools/asmgen/trgen.py)
-__device__ __forceinline__ void tr4_trace_asm(const cplx *auto_f, uint32_t split_bytes, int wave, uint32_t slot0_addr, uint32_t tile_addr)
+__device__ __forceinline__ void tr4_trace_asm(const cplx *auto_f, uint32_t split_bytes, int wave, uint32_t slot0_addr, uint32_t tile_addr, int tie_on)
 {
 #ifdef TXD_STAMPS_TRACE
     unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
@@ -650,7 +650,7 @@ __device__ __forceinline__ void tr4_trace_asm(const cplx *auto_f, uint32_t split
     asm volatile(
 #include "tx_trace_asm_stamps.inc"
         :
-        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(dbg)
+        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(tie_on), "s"(dbg)
         :
 #include "tx_trace_asm_clobbers.inc"
     );
@@ -658,14 +658,14 @@ __device__ __forceinline__ void tr4_trace_asm(const cplx *auto_f, uint32_t split
     asm volatile(
 #include "tx_trace_asm.inc"
         :
-        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr)
+        : "s"(auto_f), "s"(split_bytes), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(tie_on)
         :
 #include "tx_trace_asm_clobbers.inc"
     );
 #endif
 }
 // a8 + a9: the generated scheme-switching body on the GLev element behind `tile` (tools/asmgen/ssgen.py)
-__device__ __forceinline__ void tr4_ss_asm(const cplx *ss_f, cplx *o, int wave, uint32_t slot0_addr, uint32_t tile_addr)
+__device__ __forceinline__ void tr4_ss_asm(const cplx *ss_f, cplx *o, int wave, uint32_t slot0_addr, uint32_t tile_addr, int tie_on)
 {
 #ifdef TXD_STAMPS_SS
     unsigned long long *dbg = (blockIdx.x == TXD_STAMP_BLOCK && wave == TXD_STAMP_THREAD / 64) ? txd_stamps : txd_stamps_sink;
@@ -673,7 +673,7 @@ __device__ __forceinline__ void tr4_ss_asm(const cplx *ss_f, cplx *o, int wave, 
     asm volatile(
 #include "tx_ss_asm_stamps.inc"
         :
-        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(dbg)
+        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(tie_on), "s"(dbg)
         :
 #include "tx_trace_asm_clobbers.inc"
     );
@@ -681,7 +681,7 @@ __device__ __forceinline__ void tr4_ss_asm(const cplx *ss_f, cplx *o, int wave, 
     asm volatile(
 #include "tx_ss_asm.inc"
         :
-        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr)
+        : "s"(ss_f), "s"(o), "s"(wave), "s"(slot0_addr), "s"(tile_addr), "s"(tie_on)
         :
 #include "tx_trace_asm_clobbers.inc"
     );
@@ -704,7 +704,7 @@ __device__ __forceinline__ uint32_t lds_addr(unsigned char *p)
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g)
+void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx *auto_f, size_t split_stride, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     int wave; unsigned char *slot0;
@@ -715,7 +715,7 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
     if (!active) unit = count * CBS_L - 1;          // needed by the ring form of the loop (barriers); harmless with streamed keys
     uint64_t *gl = reinterpret_cast<uint64_t *>(tile + BR3_TILE_BYTES);
     tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
-    tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, lds_addr(slot0), lds_addr(tile));
+    tr4_trace_asm(auto_f, (uint32_t)(split_stride * sizeof(cplx)), wave, lds_addr(slot0), lds_addr(tile), tie_on);
     if (!active) return;
     uint64_t *o = glev + (size_t)unit * GL;
     const int lane2 = threadIdx.x & 63;
@@ -733,7 +733,7 @@ void k_extract_trace4(const uint64_t *acc, uint64_t *glev, int count, const cplx
 // k_scheme_switch and the oracle.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx *ss_f, const cplx *tw_g)
+void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx *ss_f, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     int wave; unsigned char *slot0;
@@ -747,7 +747,7 @@ void k_scheme_switch4(const uint64_t *glev, cplx *ggsw_f, int units, const cplx 
     for (int q = 0; q < KP; q++)
 #pragma unroll
         for (int m = 0; m < 16; m++) gl[q * N + lane + 64 * m] = gp[q * N + lane + 64 * m];
-    tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, lds_addr(slot0), lds_addr(tile));
+    tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, lds_addr(slot0), lds_addr(tile), tie_on);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -832,7 +832,7 @@ void k_lut_eval4(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride, si
 // first loads) instead of two.  What run_cbs launches; the stage entry points keep the two kernels apart.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_trace_scheme_switch4(const uint64_t *acc, cplx *ggsw_f, int count, const cplx *auto_f, size_t split_stride,
-                            const cplx *ss_f, const cplx *tw_g)
+                            const cplx *ss_f, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     int wave; unsigned char *slot0;
@@ -849,8 +849,8 @@ void k_trace_scheme_switch4(const uint64_t *acc, cplx *ggsw_f, int count, const 
         int unit = base + (int)blockIdx.x * WAVES + wave;
         if (unit >= total) unit = total - 1;
         tr4_extract_to_lds(acc + (size_t)(unit / CBS_L) * GL, unit % CBS_L, gl, lane);
-        tr4_trace_asm(auto_f, split_bytes, wave, slot0_addr, tile_addr);
-        tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, slot0_addr, tile_addr);
+        tr4_trace_asm(auto_f, split_bytes, wave, slot0_addr, tile_addr, tie_on);
+        tr4_ss_asm(ss_f, ggsw_f + (size_t)unit * KP * KP * H, wave, slot0_addr, tile_addr, tie_on);
     }
 }
 

@@ -57,6 +57,8 @@ struct WaveCtx {
     uint64_t *pl;       // same memory viewed as 1024 torus words
     int lane;
     int unit;           // global unit index of this wave
+    int tie_lane;       // lane & tie_on: parity of the coefficient index where the top-level tie goes to -B/2 (balanced rule),
+                        // 0 everywhere under tfhe-rs' rule (tx_set_decomposer_tie_rule)
 };
 
 // loads the twiddle table into LDS; returns the per-wave context.  Contains the only
@@ -74,6 +76,7 @@ __device__ __forceinline__ WaveCtx wave_setup(const cplx *tw_g, unsigned char *l
     w.pl = reinterpret_cast<uint64_t *>(w.tile);
     w.lane = threadIdx.x & 63;
     w.unit = blockIdx.x * WAVES + wave;
+    w.tie_lane = w.lane;
     return w;
 }
 
@@ -167,7 +170,7 @@ __device__ __forceinline__ void extprod_group(cplx (&F)[NCOL][8], ST (&slo)[8], 
     cplx d[P][8];
 #pragma unroll
     for (int i = 0; i < P; i++) {
-        const ST tie = (lev0 - i == 0) ? D::tie_mask(w.lane) : (ST)0;      // top level: balanced tie
+        const ST tie = (lev0 - i == 0) ? D::tie_mask(w.tie_lane) : (ST)0;  // top level: balanced tie (or none: tfhe-rs' rule)
 #pragma unroll
         for (int m = 0; m < 8; m++) d[i][m] = make_double2((double)D::next(slo[m], tie), (double)D::next(shi[m], tie));
     }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void k_fwd_torus256(const uint64_t *in, cplx *
 // ------------------------------------------------------------------------------------------
 constexpr int KS_MAXKOUT = 5;
 __global__ __launch_bounds__(256) void k_lwe_keyswitch(const uint64_t *in, uint64_t *out, int count, int n,
-                                                       const cplx *ksk_f, const cplx *tw256_g)
+                                                       const cplx *ksk_f, const cplx *tw256_g, int tie_on)
 {
     __shared__ cplx tws[192];
     for (int i = threadIdx.x; i < 192; i += blockDim.x) tws[i] = tw256_g[i];
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void k_lwe_keyswitch(const uint64_t *in, uint6
 #pragma unroll 1
         for (int i = 0; i < KS_L; i++) {
             const int lev = KS_L - 1 - i;
-            const D::state_t tie = (lev == 0) ? D::tie_mask(lane) : 0;       // top level: balanced tie
+            const D::state_t tie = (lev == 0) ? D::tie_mask(lane & tie_on) : 0;      // top level: balanced tie (tie_on = 0: tfhe-rs' rule)
             // complex point lane      = (g[lane],      g[lane + 128])  -> regs r = 0, 2
             // complex point lane + 64 = (g[lane + 64], g[lane + 192])  -> regs r = 1, 3
             double d0 = (double)D::next(st[0], tie), d1 = (double)D::next(st[1], tie);
@@ -943,10 +946,11 @@ __device__ __forceinline__ void sample_extract_store(const uint64_t (&p0)[16], c
 // pos: AES byte position (0..15) of every byte, i.e. which keyed table it takes; null = byte index mod 16 (whole blocks)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUT_WAVES_PER_EU))) void k_lut_eval(const cplx *ggsw_f, const uint64_t *luts, size_t lut_stride,
                                                   size_t byte_stride, uint64_t *out, int nbytes, int nlut,
-                                                  const cplx *tw_g, const uint8_t *pos)
+                                                  const cplx *tw_g, const uint8_t *pos, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds);
+    w.tie_lane = w.lane & tie_on;
     // XCD-aware unit order: the 2 nlut units of a byte read the same eight selector GGSWs (4 MB), and workgroups go to the eight
     // XCDs round-robin, each XCD with an L2 of its own -- in launch order the units of a byte would sit on two XCDs and every
     // GGSW would cross the fabric twice (7.4 GB per launch counted for 4.1 GB of GGSWs, profiles/r4m_pmc_fetch_size_bench_command.csv).
@@ -994,10 +998,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUT_WAVES_P
 // selector sel[u] (index into ggsw_f), GLWEs ct0[u], ct1[u] (ct1 is not modified).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUT_WAVES_PER_EU))) void k_cmux(uint64_t *ct0, const uint64_t *ct1, const cplx *ggsw_f, const int *sel,
-                                              int units, const cplx *tw_g)
+                                              int units, const cplx *tw_g, int tie_on)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     WaveCtx w = wave_setup(tw_g, lds);
+    w.tie_lane = w.lane & tie_on;
     if (w.unit >= units) return;
     uint64_t *p0 = ct0 + (size_t)w.unit * GL;
     const uint64_t *p1 = ct1 + (size_t)w.unit * GL;

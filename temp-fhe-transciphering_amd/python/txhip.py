@@ -46,7 +46,8 @@ EXPORTS = ["tx_params_aes_tight", "tx_last_error", "tx_create", "tx_destroy", "t
            "tx_max_u16_io", "tx_inner_product_u16_io", "tx_stage_circuit_bootstrap", "tx_timing_size",
            "tx_device_alloc", "tx_device_free", "tx_device_upload", "tx_device_download",
            "tx_transcipher_chunks", "tx_chunk_blocks", "tx_set_ctr_column_sharing", "tx_host_alloc", "tx_host_free",
-           "tx_device_count", "tx_host_register", "tx_host_unregister", "tx_reserve"]
+           "tx_device_count", "tx_host_register", "tx_host_unregister", "tx_reserve",
+           "tx_set_decomposer_tie_rule"]
 
 # the experiment build: the same sources with -DTXD_EXPERIMENTS (superseded kernels + TX_*_VARIANT knobs); tests and A/B tools only
 EXP_LIB_PATH = os.path.join(PKG_DIR, "libtfhe_mi355x_exp.so")
@@ -112,6 +113,7 @@ def lib(experiments=False):
         L.tx_host_register.argtypes = [C.c_void_p, C.c_size_t]
         L.tx_host_unregister.argtypes = [C.c_void_p]
         L.tx_reserve.argtypes = [C.c_void_p, C.c_size_t]
+        L.tx_set_decomposer_tie_rule.argtypes = [C.c_void_p, C.c_int]
         _LIBS[path] = L
         if not experiments:
             _LIB = L
@@ -260,6 +262,10 @@ class Engine:
 
     def reserve(self, n_blocks):
         self._chk(self.L.tx_reserve(self.h, n_blocks))
+
+    def set_decomposer_tie_rule(self, tfhe_rs):
+        """True: every decomposition follows tfhe-rs' SignedDecomposer (top-level tie always +B/2); False: balanced (default)"""
+        self._chk(self.L.tx_set_decomposer_tie_rule(self.h, 1 if tfhe_rs else 0))
 
     def set_ctr_column_sharing(self, enabled):
         self._chk(self.L.tx_set_ctr_column_sharing(self.h, 1 if enabled else 0))

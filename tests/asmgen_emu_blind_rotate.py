@@ -134,6 +134,7 @@ def main():
         emu.s[s.i] = val & 0xFFFFFFFF; emu.s[s.i + 1] = val >> 32
     emu.s[SG.NSTEP.i] = steps
     emu.s[SG.TILE.i] = TILE
+    emu.s[SG.TIEMODE.i] = 0 if os.environ.get('EMU_TIE') == 'tfhe' else 1      # tie-mode operand: 1 = balanced, 0 = tfhe-rs' rule
     fair = os.environ.get('BR_FAIR')            # '0': partner never ahead, '1': partner always ahead (both priority paths)
     prog = brgen.Gen(stamps=bool(os.environ.get('BR_STAMPS')), fair=fair is not None).build()
     if fair is not None:

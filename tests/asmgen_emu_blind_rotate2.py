@@ -85,6 +85,7 @@ def main():
                 e.s[s.i] = val & 0xFFFFFFFF; e.s[s.i + 1] = val >> 32
             e.s[SG.NSTEP.i] = steps
             e.s[SG.TILE.i] = TW_BYTES + w * brgen2.TILE_BYTES
+            e.s[SG.TIEMODE.i] = 1
             emus.append(e)
         t = time.time()
         run_pair(emus, progs, order)

@@ -98,6 +98,7 @@ def main():
             e.s[SG.NSTEP.i] = steps
             e.s[SG.TILE.i] = TW_BYTES + c * TILE_BYTES
             e.s[brgen3.TILE0.i] = TW_BYTES
+            e.s[SG.TIEMODE.i] = 0 if os.environ.get('EMU_TIE') == 'tfhe' else 1
             if os.environ.get("BR_STAMPS"):
                 dbg = np.zeros(128, np.uint8); e.g.append((0x4000_0000 + 0x1000 * c, dbg))
                 e.s[brgen.ST_DBG.i] = 0x4000_0000 + 0x1000 * c; e.s[brgen.ST_DBG.i + 1] = 0

@@ -93,6 +93,7 @@ def main():
     e = gcn.Emu(lds, [(GG, key_buf)])
     e.s[TS.AUTO.i] = GG & 0xFFFFFFFF; e.s[TS.AUTO.i + 1] = GG >> 32
     e.s[TS.WAVE.i] = 0; e.s[TS.SLOT0.i] = TW_BYTES; e.s[TS.TILE.i] = TW_BYTES
+    e.s[TS.TIEMODE.i] = 1
     if os.environ.get("BR_STAMPS"):
         import brgen
         dbg = np.zeros(128, np.uint8); e.g.append((0x4000_0000, dbg)); e.s[brgen.ST_DBG.i] = 0x4000_0000; e.s[brgen.ST_DBG.i + 1] = 0

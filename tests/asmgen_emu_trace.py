@@ -64,6 +64,7 @@ def main():
         e.s[TS.WAVE.i] = w
         e.s[TS.SLOT0.i] = TW_BYTES
         e.s[TS.TILE.i] = TW_BYTES + w * WAVE_LDS
+        e.s[TS.TIEMODE.i] = 0 if os.environ.get('EMU_TIE') == 'tfhe' else 1
         emus.append(e)
     t = time.time()
     gcn.run_group(emus, prog)

@@ -275,6 +275,8 @@ def test_round5_entry_points_without_a_gpu():
     assert L.tx_transcipher_chunks(None, None, 1, None, None, 0, cb, None) < 0 and b"null argument" in L.tx_last_error()
     assert L.tx_set_ctr_column_sharing(None, 0) < 0 and b"null context" in L.tx_last_error()
     assert L.tx_host_free(None) == 0
+    assert L.tx_set_decomposer_tie_rule(None, 0) < 0 and b"null context" in L.tx_last_error()
+    assert L.tx_reserve(None, 4) < 0 and L.tx_host_register(None, 8) < 0 and L.tx_host_unregister(None) == 0
     n = L.tx_device_count()
     import torch
     if not torch.cuda.is_available():

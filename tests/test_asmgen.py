@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -208,3 +209,91 @@ def _check_budget(progs):
                 if isinstance(x, gcn.S) and x.i not in (124, 106, 107): assert x.i + x.n <= 96, "s96..s101 are flat scratch / xnack; vcc and m0 are named"
         assert top <= budget
         assert not any(i.op.startswith("scratch_") for i in prog.ins)
+
+
+def _tie_words(B, L, rng):
+    """64 torus words, most of them exact TOP-LEVEL ties of Decomp<B, L> (the digit of level 1 is B/2 with nothing above it),
+    each with random low bits below the rounding point and random lower-level digits that do not carry into the top"""
+    total = B * L
+    words = np.zeros(64, np.uint64)
+    for lane in range(64):
+        top = (1 << (B - 1)) if lane % 8 != 7 else int(rng.integers(0, 1 << B))           # seven ties in eight lanes
+        lower = 0
+        for lev in range(L - 1):                                                           # lower digits < B/2: no carry upwards
+            lower = (lower << B) | int(rng.integers(0, 1 << (B - 1)))
+        state = (top << (B * (L - 1))) | lower
+        junk = int(rng.integers(0, 1 << (63 - total))) if total < 63 else 0                # below the rounding bit: rounds down
+        words[lane] = np.uint64(((state << (64 - total)) | junk) & 0xFFFFFFFFFFFFFFFF)
+    return words
+
+
+@pytest.mark.parametrize("tfhe", [False, True])
+def test_generated_digit_sequences_follow_the_tie_mode_operand(oracle, tfhe):
+    """tx_set_decomposer_tie_rule: the tie-mode operand of the generated loops (1 = balanced, 0 = tfhe-rs' SignedDecomposer) reaches
+    the digit sequences.  On words that ARE top-level ties -- random data meets one per 2^23 (blind rotation), 2^13 (trace) or 2^17
+    (scheme switch) coefficients -- the blind rotation's digit_pair and the trace / scheme-switching digits_bl give, lane by lane,
+    what txo_decompose_idx gives under the same rule; and the two rules differ exactly on the odd lanes that tie"""
+    sys.path.insert(0, GEN)
+    import ctypes as C
+    import gcn, brgen, trgen, ssgen
+    from gcn import V, Lit
+    L = oracle.lib()
+    L.txo_decompose_idx.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(7)
+    mode = 0 if tfhe else 1
+    oracle.set_top_digit_rule(tfhe)
+    try:
+        def want(words, B, Lv):
+            out = np.zeros((64, Lv), np.int64)
+            d = (C.c_int64 * Lv)()
+            for lane in range(64):
+                L.txo_decompose_idx(C.c_uint64(int(words[lane])), B, Lv, lane & 1, d)
+                out[lane] = list(d)
+            return out
+
+        # ---- blind rotation: digit_pair (B = 23, one level) of brgen.Gen, the prologue's own mode-dependent registers
+        g = brgen.Gen()
+        e = g.e
+        e("v_mbcnt_lo_u32_b32", brgen.LANE, Lit(-1), Lit(0)); e("v_mbcnt_hi_u32_b32", brgen.LANE, Lit(-1), brgen.LANE)
+        g.tie_lane(brgen.T0.lo())
+        e("v_lshlrev_b32", brgen.EREG, Lit(9), brgen.T0.lo()); e("v_add_u32", brgen.EREG, Lit(-0x100), brgen.EREG)
+        e("v_xor_b32", g.e_reg, Lit(1), brgen.T0.lo())
+        g.even_lanes_to_vcc()
+        g.digit_pair(V(20, 2), V(22), V(23), V(24), V(26, 2), brgen.CARRY[0])
+        words = _tie_words(23, 1, rng)
+        emu = gcn.Emu(np.zeros(64, np.uint8), [])
+        emu.s[brgen.SG.TIEMODE.i] = mode
+        if g.neg_acc:         # the loop's words are those of -acc and the sign mask is inverted: d = own' + word' with own' = 0
+            emu.v[24][:] = 0
+        emu.v[20][:] = (words & np.uint64(0xFFFFFFFF)).astype(np.uint32); emu.v[21][:] = (words >> np.uint64(32)).astype(np.uint32)
+        emu.run(g.p)
+        got = (emu.v[20].astype(np.uint64) | (emu.v[21].astype(np.uint64) << np.uint64(32))).view(np.float64)
+        exp = want(words, 23, 1)[:, 0]
+        assert np.array_equal(got, exp.astype(np.float64)), (got[:8], exp[:8])
+        ties = np.array([lane % 8 != 7 for lane in range(64)])
+        assert (np.abs(exp[ties]) == 1 << 22).all()
+        assert ((exp[ties & (np.arange(64) % 2 == 1)] > 0) == tfhe).all()          # odd lanes: -B/2 balanced, +B/2 under tfhe-rs' rule
+
+        # ---- trace (B = 13, 3 levels) and scheme switch (B = 17, 2 levels): digits_bl with the prologue's tie mask
+        for gen, B, Lv in ((trgen.TraceGen(), 13, 3), (ssgen.SsGen(), 17, 2)):
+            e = gen.e
+            e("v_mbcnt_lo_u32_b32", brgen.LANE, Lit(-1), Lit(0)); e("v_mbcnt_hi_u32_b32", brgen.LANE, Lit(-1), brgen.LANE)
+            gen.tie_lane(brgen.T0.lo(), trgen.TS.TIEMODE)
+            e("v_lshlrev_b32", trgen.TIE, Lit(B - 1), brgen.T0.lo())
+            e("s_mov_b32", trgen.TS.C_1P24, Lit(1 << (63 - B * Lv)))
+            outs = [V(40 + 2 * k, 2) for k in range(Lv)]
+            gen.digits_bl(V(20, 2), None, outs, [V(30), V(31), V(32)], brgen.CARRY[0], B, Lv)
+            words = _tie_words(B, Lv, rng)
+            emu = gcn.Emu(np.zeros(64, np.uint8), [])
+            emu.s[trgen.TS.TIEMODE.i] = mode
+            emu.v[20][:] = (words & np.uint64(0xFFFFFFFF)).astype(np.uint32); emu.v[21][:] = (words >> np.uint64(32)).astype(np.uint32)
+            emu.run(gen.p)
+            exp = want(words, B, Lv)
+            for k in range(Lv):
+                got = (emu.v[40 + 2 * k].astype(np.uint64) | (emu.v[41 + 2 * k].astype(np.uint64) << np.uint64(32))).view(np.float64)
+                assert np.array_equal(got, exp[:, k].astype(np.float64)), (B, k, got[:8], exp[:8, k])
+            top = exp[:, Lv - 1]
+            assert (np.abs(top[ties]) == 1 << (B - 1)).all()
+            assert ((top[ties & (np.arange(64) % 2 == 1)] > 0) == tfhe).all()
+    finally:
+        oracle.set_top_digit_rule(False)

@@ -109,6 +109,70 @@ def test_lut_eval_bit_identical_and_correct(rig256):
         assert np.array_equal(out_g, out_o)
 
 
+def test_tfhe_rs_decomposer_rule_is_bit_identical_to_the_oracle_under_that_rule(rig256):
+    """tx_set_decomposer_tie_rule(TX_TIE_TFHE_RS) (missing 5): every decomposition of the path then follows tfhe-rs'
+    SignedDecomposer digit for digit (a top-level tie always goes to +B/2) and every stage equals the oracle under
+    txo_set_top_digit_rule(1) bit for bit.  The launches are large enough for ties to OCCUR at every stage (one per 16
+    coefficients in the key switch, per 4 in the CBS gadget, per 2^13 in the trace, 2^17 in the scheme switch, 2^23 in the blind
+    rotation): each stage's output under the two rules DIFFERS, on the same input -- the test is not vacuous.  Then the
+    pipeline (fused trace + scheme switch, kernels by launch size), the max (k_cmux) and a decryption check."""
+    import txhip
+    r = rig256
+    O, octx, p, keys = r.O, r.octx, r.p, r.keys
+    e = txhip.Engine(txhip.aes_tight(n=p.n), 0)
+    e.load_eval_keys(keys.bsk, keys.ksk, keys.auto, keys.ss)
+    e.load_round_luts(r.luts)
+    e.load_ctr_luts(r.ctr_luts)
+    e.set_decomposer_tie_rule(True)
+    rng = np.random.default_rng(91)
+    bits = rng.integers(0, 2, 256).astype(np.uint8)             # 32 bytes: 256 units -- 600 M blind-rotation digits, about 70 ties
+    ct = O.lwe_encrypt_bits(p, keys.glwe_sk, bits, p.glwe_std, seed=19)
+    O.set_top_digit_rule(True)
+    try:
+        s_o = octx.lwe_keyswitch(ct)
+        s_g = e.lwe_keyswitch(ct)
+        assert np.array_equal(s_g, s_o) and not np.array_equal(s_g, r.eng.lwe_keyswitch(ct))
+        a_o = octx.blind_rotate(s_o)
+        a_g = e.blind_rotate(s_o)
+        assert np.array_equal(a_g, a_o)
+        n_diff = int((a_g != r.eng.blind_rotate(s_o)).any(axis=(1, 2)).sum())
+        assert n_diff >= 1, "no blind-rotation unit met a tie: enlarge the launch"
+        g_o = octx.extract_trace(a_o[:32])
+        g_g = e.extract_trace(a_o[:32])
+        assert np.array_equal(g_g, g_o) and not np.array_equal(g_g, r.eng.extract_trace(a_o[:32]))
+        f_o = octx.ggsw_to_fourier(octx.scheme_switch(g_o))
+        f_g = e.scheme_switch_fourier(g_o)
+        assert np.array_equal(f_g, f_o) and not np.array_equal(f_g, r.eng.scheme_switch_fourier(g_o))
+        gl = octx.gl
+        out_g = e.lut_eval(f_o, 0, 2, 4)
+        out_o = octx.lut_eval(f_o, r.luts[2 * 4 * 16 * 2 * gl:], 4, 2 * gl, 16 * 2 * gl)
+        assert np.array_equal(out_g, out_o) and not np.array_equal(out_g, r.eng.lut_eval(f_o, 0, 2, 4))
+        # the pipeline as tx_transcipher runs it, two blocks, two bootstrapped rounds; then CTR, whole schedule, one block
+        blk = bytes(range(32))
+        st_g = e.transcipher_partial(blk, 2)
+        assert np.array_equal(st_g, octx.transcipher_partial(r.luts, blk, 2)) and not np.array_equal(st_g, r.eng.transcipher_partial(blk, 2))
+        full = e.transcipher(blk[:16], iv=AES_IV)
+        assert np.array_equal(full, octx.transcipher_ctr(r.ctr_luts, AES_IV, blk[:16]))
+        import txclient
+        want = txclient.aes_ctr_crypt(AES_KEY, AES_IV, blk[:16])
+        got = O.lwe_decrypt_bits(keys.glwe_sk, full)
+        assert bytes(int("".join(str(int(b)) for b in got[8 * i:8 * i + 8]), 2) for i in range(16)) == want
+        # the mini-workloads' CMux kernel
+        vals = [7, 0xBEEF, 3, 0x8000]
+        vb = np.array([(v >> (15 - i)) & 1 for v in vals for i in range(16)], np.uint8)
+        vct = O.lwe_encrypt_bits(p, keys.glwe_sk, vb, p.glwe_std, seed=12)
+        mx = e.max_u16(vct)
+        assert np.array_equal(mx, octx.max_u16(vct, tournament=True)) and not np.array_equal(mx, r.eng.max_u16(vct))
+    finally:
+        O.set_top_digit_rule(False)
+    # back to the default on the same context: the balanced outputs again
+    e.set_decomposer_tie_rule(False)
+    assert np.array_equal(e.lwe_keyswitch(ct[:8]), r.eng.lwe_keyswitch(ct[:8]))
+    with pytest.raises(txhip.TxError, match="TX_TIE_BALANCED"):
+        e._chk(e.L.tx_set_decomposer_tie_rule(e.h, 7))
+    e.close()
+
+
 def test_lut_tree_kernels_agree(rig256, monkeypatch):
     """k_lut_eval4 (generated CMux tree, TX_LUT_VARIANT=4; tools/asmgen/lutgen.py) and k_lut_eval (hipcc, the default) on a launch
     of 37 bytes (a ragged last workgroup; more workgroups than XCDs, so the XCD-aware unit order matters) for every table

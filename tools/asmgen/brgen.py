@@ -51,6 +51,7 @@ class SG:
     KP0 = S(60, 2); KP1 = S(62, 2); KP2 = S(64, 2); KPN = S(66, 2)
     CS = S(44, 2); CC = S(46, 2)       # twist constants (sin, cos), set where they are used: they share CTV / TMP:TMP2, which are dead inside a transform
     FAIR = S(68); PROGA = S(69); PROGB = S(59); PBASE = S(67)   # fair mode: flag, LDS addresses of my / the partner's step counter, steps done before this unit
+    TIEMODE = S(46)      # operand, read by the prologue only (= TMP, free until then): 1 = balanced top-level tie, 0 = tfhe-rs' rule
 
 
 def f64bits(x): return struct.unpack("<Q", struct.pack("<d", x))[0]
@@ -201,8 +202,19 @@ class Gen:
         self.e("v_subb_co_u32", pair.hi(), cy, Lit(0), pair.hi(), cy)
 
     def even_lanes_to_vcc(self):
-        """vcc = the lanes with an even index: the carry-in mask of digit_pair's "+ e" (nothing else in the loops uses vcc)"""
-        self.e("s_mov_b32", VCC_LO, Lit(0x55555555)); self.e("s_mov_b32", VCC_HI, Lit(0x55555555))
+        """vcc = the lanes with e = 1: the carry-in mask of digit_pair's "+ e" (nothing else in the loops uses vcc) -- the even
+        lanes under the balanced rule, every lane under tfhe-rs' rule (TIEMODE = 0)"""
+        self.e("s_cmp_eq_u32", SG.TIEMODE, Lit(0))
+        self.e("s_cselect_b32", VCC_LO, Lit(-1), Lit(0x55555555)); self.e("s_cselect_b32", VCC_HI, Lit(-1), Lit(0x55555555))      # (-1 is an inline constant: one literal per instruction)
+
+    def tie_lane(self, dst, mode=None):
+        """dst = lane & TIEMODE: the parity bit that sends a top-level tie to -B/2 (balanced rule: odd lanes = odd coefficient
+        indices; tfhe-rs' rule: nobody).  TIEMODE arrives as an operand in a scratch register: nothing may have written it yet."""
+        mode = mode or SG.TIEMODE
+        for ins in self.p.ins:
+            assert not (ins.op.startswith("s_") and ins.a and isinstance(ins.a[0], S) and ins.a[0].i <= mode.i < ins.a[0].i + ins.a[0].n), \
+                "the tie-mode operand register was overwritten before the prologue read it: " + ins.text()
+        self.e("v_and_b32", dst, mode, LANE)
 
     def vm_wait(self, regs): pass        # kept for call sites: e() places every wait
     def lg_wait(self, regs): pass
@@ -758,7 +770,7 @@ class Gen:
         e("v_lshl_add_u32", T1.hi(), T0.lo(), Lit(6), T0.lo())  # b*65
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
-        e("v_and_b32", T0.lo(), Lit(1), LANE)
+        self.tie_lane(T0.lo())                                   # lane & 1 (balanced rule) or 0 (tfhe-rs' rule)
         e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
         e("v_add_u32", EREG, Lit(-0x100), EREG)
         if self.e_reg is not None: e("v_xor_b32", self.e_reg, Lit(1), T0.lo())
@@ -1003,12 +1015,14 @@ INPUTS = ["ct", "row", "out", "n", "tile"]     # asm operands %0..%4 ("s" constr
 
 def render_inc(prog, stamps=False, fair=False):
     """C string literal pieces of ONE asm block.  Operand copies first: %0 ct (64), %1 bsk row 0 (64), %2 out (64), %3 n, %4 tile base,
-    fair: %5 / %6 LDS addresses of this wave's / its SIMD partner's step counter, %7 steps done before this unit; stamps: then the debug buffer (64)"""
+    fair: %5 / %6 LDS addresses of this wave's / its SIMD partner's step counter, %7 steps done before this unit; then the tie mode
+    (1 = balanced top-level tie, 0 = tfhe-rs' rule); stamps: then the debug buffer (64)"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
             "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE]
     nop = 5
     if fair:
         head += ["s_mov_b32 %s, %%5" % SG.PROGA, "s_mov_b32 %s, %%6" % SG.PROGB, "s_mov_b32 %s, %%7" % SG.PBASE]; nop = 8
+    head.append("s_mov_b32 %s, %%%d" % (SG.TIEMODE, nop)); nop += 1
     if stamps: head.append("s_mov_b64 %s, %%%d" % (ST_DBG, nop))
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen.py -- do not edit"]

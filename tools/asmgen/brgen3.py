@@ -150,7 +150,7 @@ class CoopGen(Gen):
         e("v_lshl_add_u32", T1.hi(), T0.lo(), Lit(6), T0.lo())  # b*65
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), SG.TILE)
-        e("v_and_b32", T0.lo(), Lit(1), LANE)
+        self.tie_lane(T0.lo())                                   # lane & 1 (balanced rule) or 0 (tfhe-rs' rule)
         e("v_lshlrev_b32", EREG, Lit(9), T0.lo())                # 0x100 - (e << 9), e = 1 - (lane & 1)   (digit_pair)
         e("v_add_u32", EREG, Lit(-0x100), EREG)
         if self.e_reg is not None: e("v_xor_b32", self.e_reg, Lit(1), T0.lo())
@@ -420,12 +420,12 @@ class CoopGen(Gen):
 def render_inc(prog, stamps=False):
     """operands: %0 ct (64), %1 column c of bsk row 0 (64), %2 out + c N (64), %3 n, %4 this wave's tile, %5 wave 0's tile,
     %6 this CU's entry of the fairness table (64), %7 byte offset of this workgroup's word in it | key prefetch offset << 4,
-    %8 launch number << 16;
-    stamps: %9 the debug buffer (64)"""
+    %8 launch number << 16, %9 the tie mode (1 = balanced top-level tie, 0 = tfhe-rs' rule);
+    stamps: %10 the debug buffer (64)"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
             "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE, "s_mov_b32 %s, %%5" % TILE0,
-            "s_mov_b64 %s, %%6" % FTAB, "s_mov_b32 %s, %%7" % FSLOT, "s_mov_b32 %s, %%8" % FEPOCH]
-    if stamps: head.append("s_mov_b64 %s, %%9" % ST_DBG)
+            "s_mov_b64 %s, %%6" % FTAB, "s_mov_b32 %s, %%7" % FSLOT, "s_mov_b32 %s, %%8" % FEPOCH, "s_mov_b32 %s, %%9" % SG.TIEMODE]
+    if stamps: head.append("s_mov_b64 %s, %%10" % ST_DBG)
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen3.py -- do not edit"]
     for l in lines:

@@ -318,6 +318,9 @@ class Emu:
     def op_s_branch(self, lab): return lab
     def op_s_cmp_lg_u32(self, a, b): self.scc = self.sval(a) != self.sval(b)
     def op_s_cmp_eq_u32(self, a, b): self.scc = self.sval(a) == self.sval(b)
+    def op_s_cselect_b32(self, d, a, b):
+        self.s[d.i] = (self.sval(a) if self.scc else self.sval(b)) & 0xFFFFFFFF
+        if d.i in (106, 107): self._vcc_from_s()
     def op_s_cmp_gt_i32(self, a, b):
         x, y = self.sval(a), self.sval(b)
         x = x - (1 << 32) if x >> 31 else x; y = y - (1 << 32) if y >> 31 else y

@@ -224,7 +224,9 @@ class LutGen(TraceGen):
 
 def render_inc(prog, stamps=False):
     """operands: %0 the byte's eight selector GGSWs, bit 0 first (64), %1 this wave's tile; stamps: %2 the debug buffer (64)"""
-    head = ["s_mov_b64 %s, %%0" % TS.AUTO, "s_mov_b32 %s, %%1" % TS.TILE, "s_mov_b32 %s, 0" % TS.WAVE, "s_mov_b32 %s, %%1" % TS.SLOT0]
+    # (the tie mode is the constant 1 here: this experiment kernel has the balanced rule only)
+    head = ["s_mov_b64 %s, %%0" % TS.AUTO, "s_mov_b32 %s, %%1" % TS.TILE, "s_mov_b32 %s, 0" % TS.WAVE, "s_mov_b32 %s, %%1" % TS.SLOT0,
+            "s_mov_b32 %s, 1" % TS.TIEMODE]
     if stamps: head.append("s_mov_b64 %s, %%2" % brgen.ST_DBG)
     lines = ["  " + h for h in head] + ["  s_mov_b32 %s, m0" % TS.M0SAVE] + prog.render() + ["  s_mov_b32 m0, %s" % TS.M0SAVE]
     out = ["// generated by tools/asmgen/lutgen.py -- do not edit"]

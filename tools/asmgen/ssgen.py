@@ -177,10 +177,11 @@ class SsGen(TraceGen):
 
 
 def render_inc(prog, stamps=False):
-    """operands: %0 ss_f (64), %1 output of this unit (64), %2 wave index, %3 LDS address of slot 0, %4 this wave's tile"""
+    """operands: %0 ss_f (64), %1 output of this unit (64), %2 wave index, %3 LDS address of slot 0, %4 this wave's tile,
+    %5 the tie mode (1 = balanced top-level tie, 0 = tfhe-rs' rule); stamps: %6 the debug buffer"""
     head = ["s_mov_b64 %s, %%0" % TS.AUTO, "s_mov_b64 %s, %%1" % OUT, "s_mov_b32 %s, %%2" % TS.WAVE,
-            "s_mov_b32 %s, %%3" % TS.SLOT0, "s_mov_b32 %s, %%4" % TS.TILE]
-    if stamps: head.append("s_mov_b64 %s, %%5" % brgen.ST_DBG)
+            "s_mov_b32 %s, %%3" % TS.SLOT0, "s_mov_b32 %s, %%4" % TS.TILE, "s_mov_b32 %s, %%5" % TS.TIEMODE]
+    if stamps: head.append("s_mov_b64 %s, %%6" % brgen.ST_DBG)
     lines = ["  " + h for h in head] + ["  s_mov_b32 %s, m0" % TS.M0SAVE] + prog.render() + ["  s_mov_b32 m0, %s" % TS.M0SAVE]
     out = ["// generated by tools/asmgen/ssgen.py -- do not edit"]
     for l in lines: out.append('"%s\\n"' % l.replace('"', '\\"'))

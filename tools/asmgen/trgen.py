@@ -45,6 +45,7 @@ GL = brgen.BODY                            # the GLWE follows the tile
 class TS:      # scalar registers of this loop (constants at 48..58 and carries at 88..95 as brgen)
     AUTO = S(34, 2); SPLIT = S(36); WAVE = S(38); SLOT0 = S(39); IDX = S(41); TILE = SG.TILE; TINV = S(43); C64 = S(44)
     T = S(45); T2 = S(46)
+    TIEMODE = S(46)       # operand, read by the prologue only (= T2, free until then): 1 = balanced top-level tie, 0 = tfhe-rs' rule
     KP_ = S(60, 2); PB = S(62, 2); GLB = S(40); C_M2P32 = S(64, 2); M0A = S(66); C_1P24 = S(67); C_2M32 = S(68, 2); M0SAVE = S(47)
 
 
@@ -301,7 +302,7 @@ class TraceGen(Gen):
         e("v_lshl_add_u32", T1.hi(), T0.lo(), Lit(6), T0.lo())  # b*65
         e("v_add_u32", T1.lo(), T1.hi(), T1.lo())               # b*65 + g8
         e("v_lshl_add_u32", XLW, T1.lo(), Lit(4), TS.TILE)
-        e("v_and_b32", T0.lo(), Lit(1), LANE)
+        self.tie_lane(T0.lo(), TS.TIEMODE)                      # lane & 1 (balanced rule) or 0 (tfhe-rs' rule)
         e("v_lshlrev_b32", TIE, Lit(self.DIG_B - 1), T0.lo())   # tie_mask: (lane & 1) << (B - 1)
         for s_ in range(4):
             e("s_add_u32", TS.T, TS.SLOT0, Lit(s_ * WAVE_LDS))
@@ -556,10 +557,11 @@ class TraceGen(Gen):
 
 
 def render_inc(prog, stamps=False):
-    """operands: %0 auto_f (64), %1 split stride in bytes, %2 wave index, %3 LDS address of slot 0 (= wave 0's tile), %4 this wave's tile"""
+    """operands: %0 auto_f (64), %1 split stride in bytes, %2 wave index, %3 LDS address of slot 0 (= wave 0's tile), %4 this wave's tile,
+    %5 the tie mode (1 = balanced top-level tie, 0 = tfhe-rs' rule); stamps: %6 the debug buffer"""
     head = ["s_mov_b64 %s, %%0" % TS.AUTO, "s_mov_b32 %s, %%1" % TS.SPLIT, "s_mov_b32 %s, %%2" % TS.WAVE,
-            "s_mov_b32 %s, %%3" % TS.SLOT0, "s_mov_b32 %s, %%4" % TS.TILE]
-    if stamps: head.append("s_mov_b64 %s, %%5" % brgen.ST_DBG)
+            "s_mov_b32 %s, %%3" % TS.SLOT0, "s_mov_b32 %s, %%4" % TS.TILE, "s_mov_b32 %s, %%5" % TS.TIEMODE]
+    if stamps: head.append("s_mov_b64 %s, %%6" % brgen.ST_DBG)
     # M0 carries the LDS-DMA destinations: saved and restored around the loop (it is not on the clobber list)
     lines = ["  " + h for h in head] + ["  s_mov_b32 %s, m0" % TS.M0SAVE] + prog.render() + ["  s_mov_b32 m0, %s" % TS.M0SAVE]
     out = ["// generated by tools/asmgen/trgen.py -- do not edit"]
