@@ -287,7 +287,7 @@ template <class F> void on_threads(size_t n, F fn)
 
 // result file written piecewise: the chunks of all devices go to disjoint ranges (pwrite), each as soon as it has arrived
 struct ResultFile {
-    int fd = -1; std::string path;
+    int fd = -1; std::string path; bool complete = false;
     void create(const std::string &p, size_t words)
     {
         path = p;
@@ -316,8 +316,8 @@ struct ResultFile {
             if (b > a) put_range(src + a, word0 + a, b - a);
         });
     }
-    void finish() { if (fd >= 0 && close(fd) != 0) { fd = -1; throw std::runtime_error("short write " + path); } fd = -1; }
-    ~ResultFile() { if (fd >= 0) close(fd); }
+    void finish() { if (fd >= 0 && close(fd) != 0) { fd = -1; throw std::runtime_error("short write " + path); } fd = -1; complete = true; }
+    ~ResultFile() { if (fd >= 0) close(fd); if (!complete && !path.empty()) unlink(path.c_str()); }      // a failed stage leaves no half-written result
 };
 
 // Landing area of a slab's result LWEs: an anonymous mapping, page-locked REGION BY REGION (one workspace chunk each) on a

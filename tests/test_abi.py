@@ -316,3 +316,32 @@ def test_stage_device_list_parsing(tmp_path):
     (tmp_path / "datasets" / "toy" / "db.hex").write_text("00" * 16)
     r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "public_keys/ksk.bin" in r.stderr
+
+
+def test_server_stage_fails_loudly_on_a_bad_device_list_and_without_a_gpu(tmp_path):
+    """the in-process sharding of the server stages (host/stages.cpp): with real key files from the CLIENT stages (CPU only), a
+    malformed TX_DEVICES is exit status 1 with a message before any GPU work, and on a box without a HIP device the stage exits 1
+    with the no-fallback message -- never a crash, never a silent CPU path"""
+    import subprocess
+    import torch
+    binp = os.path.join(ROOT, "temp-fhe-transciphering_amd", "bin")
+    os.makedirs(tmp_path / "datasets" / "toy")
+    (tmp_path / "datasets" / "toy" / "aes_key.hex").write_text("dc937b59892604f5a86ac96936cd7ff0")
+    (tmp_path / "datasets" / "toy" / "db.hex").write_text("e907e226bb17b0e43f99940eab33ed6a")
+    env = dict(os.environ, TX_SEED="77")
+    for stage in ("client_preprocess", "client_key_generation", "client_encode_encrypt", "server_preprocess_dataset"):
+        r = subprocess.run([os.path.join(binp, stage), "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, stage + r.stderr
+    exe = os.path.join(binp, "server_encrypted_aes_decryption")
+    for bad, msg in (("0,,1", "not a comma-separated list"), ("a", "not a comma-separated list"), ("0,", "ends with a comma"), ("", "TX_DEVICES is empty")):
+        r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, env=dict(env, TX_DEVICES=bad), timeout=120)
+        assert r.returncode == 1 and msg in r.stderr, (bad, r.returncode, r.stderr)
+    if not torch.cuda.is_available():
+        for dv in (None, "0", "0,1"):
+            e2 = dict(env) if dv is None else dict(env, TX_DEVICES=dv)
+            e2.pop("TX_DEVICE", None)
+            r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, env=e2, timeout=120)
+            assert r.returncode == 1 and ("no HIP device" in r.stderr or "no such HIP device" in r.stderr), (dv, r.returncode, r.stderr)
+            assert not os.path.exists(tmp_path / "io" / "toy" / "ciphertext_aes_download" / "result.bin")      # no half-written result
+        r = subprocess.run([os.path.join(binp, "server_encrypted_compute"), "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 1
