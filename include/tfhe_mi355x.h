@@ -236,8 +236,8 @@ int tx_get_timing(tx_ctx *c, tx_timing *t);
  * by launch size (in the experiment build also by TX_BR_VARIANT): the measurement reports what ran, not what a copy of the rule predicts. */
 const char *tx_last_blind_rotate_kernel(const tx_ctx *c);
 /* Host logic of that dispatch, exposed for tests and tooling (no context, no GPU): the launches a blind rotation of `count`
- * units is split into on a chip of num_cus CUs -- kernel number (5 = k_blind_rotate5, 6 = k_blind_rotate6, 7 = k_blind_rotate7, 0 = k_blind_rotate)
- * and units of each, in unit order (round 4: 7 = k_blind_rotate7 between three and four units per CU); both arrays hold two entries.  Returns the number of launches (0..2), negative on error. */
+ * units is split into on a chip of num_cus CUs -- kernel number (5 = k_blind_rotate5, 6 = k_blind_rotate6, 8 = k_blind_rotate8)
+ * and units of each, in unit order (round 5: 8 = k_blind_rotate8 between three and four units per CU, where round 4 had k_blind_rotate7); both arrays hold two entries.  Returns the number of launches (0..2), negative on error. */
 int tx_plan_blind_rotate(size_t count, int num_cus, int *variants, size_t *counts);
 
 /* the forward-transform twiddle table [15][64] complex used by the kernels (for table pinning): eight pass-A rows

@@ -160,11 +160,12 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
 #ifdef TXD_EXPERIMENTS
     // experiment knobs (the -DTXD_EXPERIMENTS build only: libtfhe_mi355x_exp.so), parsed once and validated here (behind the
     // stream and the tables, so that a bad value also exercises the release of a half-built context)
-    if (env_knob("TX_BR_VARIANT", 0, 7, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
+    if (env_knob("TX_BR_VARIANT", 0, 8, c->br_variant) || env_knob("TX_TRACE_VARIANT", 0, 4, c->trace_variant) ||
         env_knob("TX_SS_VARIANT", 0, 4, c->ss_variant) || env_knob("TX_LUT_VARIANT", 0, 4, c->lut_variant) || env_knob("TX_BR5_WGS", 1, 1 << 20, c->br5_wgs) ||
         env_knob("TX_TRSS_WGS_PER_CU", 1, 64, c->trss_wgs_per_cu) || env_knob("TX_CTR_SHARE", 0, 1, c->ctr_share)) { tx_destroy(c); return nullptr; }
     {
-        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6 || c->br_variant == 7);
+        bool ok = (c->br_variant == -1 || c->br_variant == 0 || c->br_variant == 4 || c->br_variant == 5 || c->br_variant == 6 || c->br_variant == 7 ||
+                   c->br_variant == 8);
 #ifdef TXD_WITH_BR3
         ok = ok || c->br_variant == 3;
 #endif
@@ -187,7 +188,7 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
     };
     bool ok = lds_attr(reinterpret_cast<const void *>(k_blind_rotate5), LDS_BYTES_BR5) &&
               lds_attr(reinterpret_cast<const void *>(k_blind_rotate6), LDS_BYTES_BR6) &&
-              lds_attr(reinterpret_cast<const void *>(k_blind_rotate7), LDS_BYTES_BR7) &&
+              lds_attr(reinterpret_cast<const void *>(k_blind_rotate8), LDS_BYTES_BR7) &&
               lds_attr(reinterpret_cast<const void *>(k_extract_trace4), LDS_BYTES_TR4) &&
               lds_attr(reinterpret_cast<const void *>(k_scheme_switch4), LDS_BYTES_TR4) &&
               lds_attr(reinterpret_cast<const void *>(k_trace_scheme_switch4), LDS_BYTES_TR4);
@@ -196,6 +197,7 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
          lds_attr(reinterpret_cast<const void *>(k_trace), LDS_BYTES_TRACE) &&
          lds_attr(reinterpret_cast<const void *>(k_blind_rotate), LDS_BYTES_BR) &&
          lds_attr(reinterpret_cast<const void *>(k_blind_rotate4), LDS_BYTES_BR3) &&
+         lds_attr(reinterpret_cast<const void *>(k_blind_rotate7), LDS_BYTES_BR7) &&
          lds_attr(reinterpret_cast<const void *>(k_lut_eval4), LDS_BYTES_TR4);
 #ifdef TXD_WITH_BR3
     ok = ok && lds_attr(reinterpret_cast<const void *>(k_blind_rotate3), LDS_BYTES_BR3);
@@ -552,7 +554,7 @@ static int br_plan(size_t count, int cus_, int forced, int variants[2], size_t c
 {
     if (count == 0) return 0;
     const size_t cus = (size_t)(cus_ > 0 ? cus_ : 1);
-    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 7; };
+    auto small = [&](size_t k) { return k <= 3 * cus ? 6 : 8; };
     if (forced >= 0) { variants[0] = forced; counts[0] = count; return 1; }
     if (count <= 4 * cus) { variants[0] = small(count); counts[0] = count; return 1; }
     const size_t pass = 8 * cus, rem = count % pass, full = count - rem;
@@ -576,15 +578,15 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
 {
     const int n = (int)c->p.n;
 #ifdef TXD_EXPERIMENTS
-    br_used(c, variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" : variant == 4 ? "k_blind_rotate4" :
-               variant == 3 ? "k_blind_rotate3" : "k_blind_rotate", count);
+    br_used(c, variant == 8 ? "k_blind_rotate8" : variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : variant == 5 ? "k_blind_rotate5" :
+               variant == 4 ? "k_blind_rotate4" : variant == 3 ? "k_blind_rotate3" : "k_blind_rotate", count);
 #else
-    br_used(c, variant == 7 ? "k_blind_rotate7" : variant == 6 ? "k_blind_rotate6" : "k_blind_rotate5", count);
+    br_used(c, variant == 8 ? "k_blind_rotate8" : variant == 6 ? "k_blind_rotate6" : "k_blind_rotate5", count);
 #endif
-    if (variant == 7) {
-        ev_begin(c, F_BR, "k_blind_rotate7", count);
-        hipLaunchKernelGGL(k_blind_rotate7, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
-                           c->bsk_f, c->tw, c->fair_tab, c->tie_on);
+    if (variant == 8) {
+        ev_begin(c, F_BR, "k_blind_rotate8", count);
+        hipLaunchKernelGGL(k_blind_rotate8, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
+                           c->bsk_f, c->tw, c->tie_on);
     } else if (variant == 6) {
         // launch number 0 = no arbitration: with at most one workgroup per CU there is nobody to be fair to
         uint32_t ep = count <= (size_t)c->num_cus ? 0u : (++c->br6_epoch & 0x7FFFu);          // 15 bits above the 16-bit step count of a table word
@@ -601,6 +603,10 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
         ev_begin(c, F_BR, "k_blind_rotate5", count);
         hipLaunchKernelGGL(k_blind_rotate5, dim3(wgs), dim3(512), LDS_BYTES_BR5, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw, c->tie_on);
 #ifdef TXD_EXPERIMENTS
+    } else if (variant == 7) {
+        ev_begin(c, F_BR, "k_blind_rotate7", count);
+        hipLaunchKernelGGL(k_blind_rotate7, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
+                           c->bsk_f, c->tw, c->fair_tab, c->tie_on);
     } else if (variant == 4) {
         ev_begin(c, F_BR, "k_blind_rotate4", count);
         hipLaunchKernelGGL(k_blind_rotate4, dim3(grid_for(count)), dim3(256), LDS_BYTES_BR3, c->stream, in, acc, (int)count, n, c->bsk_f, c->tw, c->tie_on);
@@ -629,10 +635,11 @@ static void run_br(tx_ctx *c, const uint64_t *in, size_t count, uint64_t *acc)
     //         polynomial (tx_br2.hpp), and (round 4) keeps the workgroups of a CU level through a table of step counters and
     //         s_setprio: 128 and 256 units 2.9 against 7.1 ms for the one-wave kernel, 512 units 4.0 (4.5 without the
     //         fairness), 768 units 4.9 (5.8 without).  One workgroup per CU has nobody to be fair to (launch number 0).
-    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) k_blind_rotate7: the same loop with the four units
+    //   3..4  (the 8-blocks-per-GPU share of the medium instance: 1024 units) k_blind_rotate8: the same loop with the four units
     //         of a CU in ONE twelve-wave workgroup -- four independent three-wave workgroups need a packing of 168-register
-    //         waves the hardware's placement misses for a handful of workgroups per launch (9 ms instead of 6.5): 6.9 ms
-    //         against 7.5 ms for k_blind_rotate (one wave per unit, hipcc; TX_BR_VARIANT=0: the plain form of the algorithm).
+    //         waves the hardware's placement misses for a handful of workgroups per launch (9 ms instead of 6.5) -- and, since
+    //         round 5, software barriers per unit instead of the workgroup's s_barrier (k_blind_rotate7: lockstep): 5.9 ms
+    //         against 6.4 for k_blind_rotate7 and 7.5 for k_blind_rotate (one wave per unit, hipcc), inside the pipeline.
     // A large launch that does not fill its last pass of 8 units per CU is split: whole passes go to k_blind_rotate5, and a
     // remainder of at most 4 units per CU to the small-launch kernels behind it (a persistent wave would otherwise take one
     // more 10.7 ms unit for it: 2144 units = 21.4 ms unsplit, 10.7 + 2.9 ms split).

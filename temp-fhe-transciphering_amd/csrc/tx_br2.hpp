@@ -528,6 +528,7 @@ void k_blind_rotate6(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 #endif
 }
 
+// (k_blind_rotate7 itself is superseded by k_blind_rotate8 below and lives in the experiment build only; its constants serve both)
 // ------------------------------------------------------------------------------------------
 // k_blind_rotate7: the cooperative loop of k_blind_rotate6 with FOUR units in one workgroup of twelve waves (768 threads, one
 // workgroup per CU), for launches of exactly four units per CU -- the 8-blocks-per-GPU share of the medium instance: 1024 units.
@@ -548,6 +549,7 @@ constexpr int BR7_UNITS = 4;
 static_assert(BR6_PF_ROWS == 0, "k_blind_rotate7 passes the unit's own tiles as TILE0: a key prefetch would dump into the next unit's tile");
 constexpr size_t LDS_BYTES_BR7 = BR3_TW_CPLX * sizeof(cplx) + BR7_UNITS * BR6_WAVES * BR3_TILE_BYTES + 1024;
 
+#ifdef TXD_EXPERIMENTS   // superseded by k_blind_rotate8 (lockstep: 6.44 against 5.9 ms in the pipeline)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, uint32_t *fair_tab, int tie_on)
 {
@@ -608,6 +610,69 @@ void k_blind_rotate7(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
 #include "tx_br3_asm_clobbers.inc"
     );
 #endif
+}
+#endif  // TXD_EXPERIMENTS
+
+__device__ __forceinline__ uint32_t lds_addr(unsigned char *p)
+{
+    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)p);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blind_rotate8 (round 5; what run_br launches between three and four units per CU -- the 8-blocks-per-GPU share of the medium
+// instance: 1024 units): four units in ONE twelve-wave workgroup per CU, three waves per SIMD by construction (k_blind_rotate7's
+// shape, section "Placement" of DESIGN_HISTORY.md) -- WITHOUT k_blind_rotate7's lockstep: the generated loop's soft-barrier form (tools/asmgen/brgen3.py, SOFT: tx_br3s_asm.inc).
+// The three waves of a unit meet at arrival words in LDS that they poll (s_sleep between polls), the four units drift apart and
+// fill each other's stalls, and the fair arbitration between them reads their step counters from LDS.  No s_barrier behind the
+// __syncthreads below; a wave gives up polling after 2^18 tries (wrong results, never a launch that does not end).  Same
+// arithmetic, same results.  Inside the round pipeline 5.85-5.95 ms per 1024 units against 6.44 for k_blind_rotate7 (same box,
+// alternating, profiles/r5g_*); without the fair arbitration 6.8 ms.  The spare kilobyte behind the twelve tiles holds the arrival words (16 bytes per unit) and the four
+// step counters.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_blind_rotate8(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, int tie_on)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    cplx *tw = reinterpret_cast<cplx *>(lds);
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) tw[i] = tw_g[i];
+    if (threadIdx.x < 7 * 8) tw[BR3_TWB + threadIdx.x] = tw_g[(8 + (threadIdx.x >> 3)) * 64 + (threadIdx.x & 7)];
+    unsigned char *sync = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)(BR7_UNITS * BR6_WAVES) * BR3_TILE_BYTES;      // the spare kilobyte
+    if (threadIdx.x < 5 * BR7_UNITS) reinterpret_cast<uint32_t *>(sync)[threadIdx.x] = 0;                            // arrival words + step counters
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int u = wave / BR6_WAVES, c = wave % BR6_WAVES;
+    const int unit = min((int)blockIdx.x * BR7_UNITS + u, count - 1);
+    unsigned char *tile0 = lds + BR3_TW_CPLX * sizeof(cplx) + (size_t)(u * BR6_WAVES) * BR3_TILE_BYTES;
+    unsigned char *tile = tile0 + (size_t)c * BR3_TILE_BYTES;
+    uint64_t *pl = reinterpret_cast<uint64_t *>(tile);
+    const uint64_t *ct = lwe + (size_t)unit * (n + 1);
+    if (c == KP - 1) {      // acc = (0, 0, TV * X^(-b~))      pbs.rs:84-101
+        const int rot = 2 * N - (int)modswitch(ct[n]);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int src = lane + 64 * m - rot;
+            uint64_t neg = 0;
+            if (src < 0) { src += N; neg = ~neg; }
+            if (src < 0) { src += N; neg = ~neg; }
+            uint64_t x = test_vector(src);
+            pl[lane + 64 * m] = (x ^ neg) - neg;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) pl[lane + 64 * m] = 0;
+    }
+    __syncthreads();
+    const uint32_t tile_addr = lds_addr(tile), tile0_addr = lds_addr(tile0);
+    const uint32_t flags = lds_addr(sync + 16 * u), myflag = flags + 4u * (uint32_t)c;
+    const uint32_t prog = lds_addr(sync + 16 * BR7_UNITS), myprog = prog + 4u * (uint32_t)u;
+    const cplx *col = bsk_f + (size_t)c * H;
+    uint64_t *out = acc_out + (size_t)unit * GL + (size_t)c * N;
+    asm volatile(
+#include "tx_br3s_asm.inc"
+        :
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(flags), "s"(myflag), "s"(prog), "s"(myprog), "s"(tie_on)
+        :
+#include "tx_br3_asm_clobbers.inc"
+    );
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,10 +762,6 @@ __device__ __forceinline__ unsigned char *tr4_setup(unsigned char *lds, const cp
     wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     slot0 = lds + BR3_TW_CPLX * sizeof(cplx);
     return slot0 + (size_t)wave * TR4_WAVE_BYTES;
-}
-__device__ __forceinline__ uint32_t lds_addr(unsigned char *p)
-{
-    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)p);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))

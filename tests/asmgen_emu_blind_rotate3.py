@@ -27,6 +27,28 @@ TILE_BYTES = 8320
 LDS_BYTES = TW_BYTES + 3 * TILE_BYTES + 1024 + 16        # + the dump area of the key prefetch + the workgroup's fairness slot
 
 
+def run_group_soft(emus, prog, order):
+    """soft-barrier form: no s_barrier in the loop; a wave that polls yields at its s_sleep and the next one (in `order`) runs.
+    A full round in which every live wave only slept is a deadlock."""
+    for e in emus: e.yield_on_sleep = True
+    gens = [e.run_gen(prog) for e in emus]
+    alive = [True] * len(gens)
+    idle_rounds = 0
+    while any(alive):
+        progressed = False
+        for k in order:
+            if not alive[k]: continue
+            before = emus[k].nexec
+            try:
+                st = next(gens[k])
+                assert st == "sleep", st
+            except StopIteration:
+                alive[k] = False
+            progressed = progressed or emus[k].nexec - before > 16 or not alive[k]
+        idle_rounds = 0 if progressed else idle_rounds + 1
+        if idle_rounds > 4: raise RuntimeError("every wave is polling: deadlock")
+
+
 def run_group_ordered(emus, prog, order):
     gens = [e.run_gen(prog) for e in emus]
     alive = [True] * len(gens)
@@ -67,8 +89,10 @@ def main():
     for i in range(N):
         v = np.uint64(1) << np.uint64(63 - 2 * ((i & 7) + 1))
         tv[i] = (np.uint64(0) - v) if i < N // 2 else v
-    gen = brgen3.CoopGen(stamps=bool(os.environ.get("BR_STAMPS")))
+    SOFT = os.environ.get("BR3_SOFT") == "1"        # k_blind_rotate8's loop: software barriers per unit, LDS step counters
+    gen = brgen3.CoopGen(stamps=bool(os.environ.get("BR_STAMPS")), soft=SOFT)
     prog, prog_fair = gen.build(), gen.cu_fair
+    FLAGS = TW_BYTES + 3 * TILE_BYTES                # (the emulated workgroup's spare kilobyte) arrival words, then the step counters
     ok = True
     for order in ([0, 1, 2], [2, 1, 0]):
         lds = np.zeros(LDS_BYTES, np.uint8)
@@ -99,11 +123,25 @@ def main():
             e.s[SG.TILE.i] = TW_BYTES + c * TILE_BYTES
             e.s[brgen3.TILE0.i] = TW_BYTES
             e.s[SG.TIEMODE.i] = 0 if os.environ.get('EMU_TIE') == 'tfhe' else 1
+            if SOFT:
+                e.s[brgen3.SFLAGS.i] = FLAGS; e.s[brgen3.SMYFLAG.i] = FLAGS + 4 * c
+                e.s[brgen3.SPROG.i] = FLAGS + 16; e.s[brgen3.SMYPROG.i] = FLAGS + 16 + 4 * 1        # this unit is unit 1 of its workgroup
             if os.environ.get("BR_STAMPS"):
                 dbg = np.zeros(128, np.uint8); e.g.append((0x4000_0000 + 0x1000 * c, dbg))
                 e.s[brgen.ST_DBG.i] = 0x4000_0000 + 0x1000 * c; e.s[brgen.ST_DBG.i + 1] = 0
             emus.append(e)
         t = time.time()
+        if SOFT:
+            # the other units' step counters: one two steps ahead, one finished, one behind (every priority path over three steps)
+            lds[FLAGS + 16: FLAGS + 32].view(np.uint32)[:] = [2, 0, 0xFFFFFFF0, 0]
+            run_group_soft(emus, prog, order)
+            same = np.array_equal(out_buf.view(np.uint64).reshape(KP, N), ref)
+            cnt = lds[FLAGS: FLAGS + 32].view(np.uint32)
+            same = same and list(cnt[:3]) == [2 * steps] * 3 and cnt[4 + 1] == 0xFFFFFFF0 and cnt[4] == 2 and cnt[4 + 2] == 0xFFFFFFF0
+            ok = ok and same
+            print("soft barriers, steps %d seed %d order %s: %d instructions per wave, %.1f s -> %s" %
+                  (steps, seed, order, emus[0].nexec, time.time() - t, "BIT-IDENTICAL" if same else "MISMATCH"))
+            continue
         run_group_ordered(emus, prog, order)
         got = out_buf.view(np.uint64).reshape(KP, N)
         same = np.array_equal(got, ref)

@@ -235,10 +235,10 @@ def test_blind_rotation_launch_plan():
     P = txhip.plan_blind_rotate
     assert P(0) == []
     assert P(128) == [(6, 128)] and P(768) == [(6, 768)]                     # up to three units per CU: three waves per unit
-    assert P(769) == [(7, 769)] and P(1024) == [(7, 1024)]                   # three to four: four units per twelve-wave workgroup
+    assert P(769) == [(8, 769)] and P(1024) == [(8, 1024)]                   # three to four: four units per twelve-wave workgroup, soft barriers
     assert P(1025) == [(5, 1025)] and P(2048) == [(5, 2048)] and P(8192) == [(5, 8192)]
     assert P(2144) == [(5, 2048), (6, 96)]                                   # medium CTR, shared round: a whole pass + the ragged rest
-    assert P(2048 + 1000) == [(5, 2048), (7, 1000)]
+    assert P(2048 + 1000) == [(5, 2048), (8, 1000)]
     assert P(2048 + 1025) == [(5, 3073)]                                     # the rest is worth a pass of its own
     assert P(4 * 2048 + 352) == [(5, 8192), (6, 352)]
     for count in list(range(1, 5000, 37)) + [16384, 16384 + 500]:
@@ -295,10 +295,10 @@ def test_product_library_has_no_experiment_surface():
         assert knob not in prod, knob
         assert knob in exp, knob
     assert b"getenv" not in prod                       # the product library reads no environment at all
-    for kernel in (b"k_blind_rotate4", b"k_lut_eval4", b"15k_extract_trace", b"15k_scheme_switch", b"7k_trace"):
+    for kernel in (b"k_blind_rotate4", b"k_blind_rotate7", b"k_lut_eval4", b"15k_extract_trace", b"15k_scheme_switch", b"7k_trace"):
         assert kernel not in prod, kernel
         assert kernel in exp, kernel
-    for kernel in (b"k_blind_rotate5", b"k_blind_rotate6", b"k_blind_rotate7", b"k_trace_scheme_switch4", b"k_lut_eval", b"k_extract_trace4"):
+    for kernel in (b"k_blind_rotate5", b"k_blind_rotate6", b"k_blind_rotate8", b"k_trace_scheme_switch4", b"k_lut_eval", b"k_extract_trace4"):
         assert kernel in prod, kernel
     Lx = txhip.lib(experiments=True)
     for s in declared_symbols():

@@ -51,6 +51,29 @@ def test_cooperative_loop_equals_oracle_three_waves(oracle):
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
 
 
+def test_cooperative_loop_with_soft_barriers_equals_oracle(oracle):
+    """the soft-barrier form of that loop (k_blind_rotate8: the unit's three waves meet at arrival words in LDS they poll, the
+    units of a workgroup are kept level through step counters in LDS; csrc/tx_br3s_asm.inc): three emulated waves, a wave that
+    polls in vain yields to the next one, both scheduling orders; the arrival words end at two per step, the unit's counter at
+    "finished", the other units' counters untouched; without the barriers (ablation) it must NOT match.  The emulator also
+    refuses what the first version of this loop did on the hardware: a v_readfirstlane_b32 of a register the instruction
+    before it wrote (one wait state on gfx940+: it read the OLD value and every poll passed at once)"""
+    exe = os.path.join(ROOT, "tests", "asmgen_emu_blind_rotate3.py")
+    for steps, seed in ((3, 1), (2, 77)):
+        r = subprocess.run([sys.executable, exe, str(steps), str(seed)], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR3_SOFT="1"))
+        assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, exe, "2", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR3_SOFT="1", BR3_ABL="B"))
+    assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
+    sys.path.insert(0, GEN)
+    import gcn
+    from gcn import V, S, Lit
+    p = gcn.Prog()
+    p.emit("v_mov_b32", V(13), Lit(5))
+    p.emit("v_readfirstlane_b32", S(46), V(13))
+    with pytest.raises(gcn.Poison, match="1 wait state"):
+        gcn.Emu(np.zeros(64, np.uint8), []).run(p)
+
+
 @pytest.mark.experiments
 def test_paired_loops_equal_oracle_two_waves(oracle):
     """tools/asmgen/brgen2.py (two waves per unit, A = the mask polynomials and columns 0, 1, B = the body and column 2; two
@@ -121,7 +144,7 @@ def test_committed_assembly_is_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(GEN, "lutgen.py"), "--out", str(tmp_path)])
     # (the *_stamps.inc diagnostic variants the generators also write are build-time output, not tracked)
     for f in ("tx_fft_consts.inc", "tx_ss_asm.inc", "tx_br_asm.inc", "tx_br_asm_fair.inc", "tx_br_asm_clobbers.inc",
-              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3_asm_clobbers.inc", "tx_br3_asm_consts.inc", "tx_lut_asm.inc"):
+              "tx_trace_asm.inc", "tx_trace_asm_clobbers.inc", "tx_br3_asm.inc", "tx_br3s_asm.inc", "tx_br3_asm_clobbers.inc", "tx_br3_asm_consts.inc", "tx_lut_asm.inc"):
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(CSRC, f)).read(), f + " is stale: run tools/asmgen/brgen.py --out csrc"
 
 
@@ -170,17 +193,17 @@ def test_scratch_of_the_built_kernels():
         hits = [v for n, v in k.items() if stem in n]
         assert len(hits) == 1, (stem, sorted(k))
         return hits[0]
-    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate6", "15k_blind_rotate7"):
+    for stem in ("16k_extract_trace4", "16k_scheme_switch4", "22k_trace_scheme_switch4", "15k_blind_rotate6", "15k_blind_rotate8"):
         assert find(stem)["private_segment_fixed_size"] == 0, stem
     assert find("15k_blind_rotate5")["private_segment_fixed_size"] <= 128
     assert find("15k_blind_rotate5")["vgpr_count"] == 256
     assert find("15k_blind_rotate6")["vgpr_count"] == 168            # three waves per SIMD
-    assert find("15k_blind_rotate7")["vgpr_count"] == 168            # twelve waves of one workgroup: three per SIMD
+    assert find("15k_blind_rotate8")["vgpr_count"] == 168            # twelve waves of one workgroup: three per SIMD
     # the product library holds none of the superseded kernels; the experiment build holds them, built to the same budgets
-    assert not [n for n in k if "15k_blind_rotate4" in n or "11k_lut_eval4" in n or "15k_extract_traceE" in n]
+    assert not [n for n in k if "15k_blind_rotate4" in n or "15k_blind_rotate7" in n or "11k_lut_eval4" in n or "15k_extract_traceE" in n]
     kx = _code_object_kernels("libtfhe_mi355x_exp.so")
     assert find("15k_blind_rotate4", kx)["private_segment_fixed_size"] == 0 and find("15k_blind_rotate4", kx)["vgpr_count"] == 256
-    assert find("15k_blind_rotate5", kx)["vgpr_count"] == 256 and find("22k_trace_scheme_switch4", kx)["private_segment_fixed_size"] == 0
+    assert find("15k_blind_rotate7", kx)["vgpr_count"] == 168 and find("15k_blind_rotate5", kx)["vgpr_count"] == 256 and find("22k_trace_scheme_switch4", kx)["private_segment_fixed_size"] == 0
 
 
 def test_register_budget_and_no_scratch():

@@ -214,7 +214,7 @@ def test_partial_schedule_bit_identical_full_parameters(rig768):
 def test_repeat_runs_are_bit_identical(rig768):
     """the kernels' wave priorities, the fair tables (keyed by hardware CU ids, reused across launches with an epoch) and the dispatch by
     launch size may change timing, never results: the same ciphertexts through the full schedule three times, ECB and CTR, sizes that
-    take k_blind_rotate6 (1 block) and k_blind_rotate7 / 5 (8 blocks: 1024 units, then the shared round's smaller launch)"""
+    take k_blind_rotate6 (1 block) and k_blind_rotate8 / 5 (8 blocks: 1024 units, then the shared round's smaller launch)"""
     r = rig768
     rng = np.random.default_rng(77)
     for nb in (1, 8):
@@ -711,7 +711,7 @@ def test_inner_product_matches_oracle_and_fixture(rig256, rig768):
 def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     """BASELINE config 4's per-GPU share on one card: 31 blocks over FOUR ranks (gloo; a GPU box admits at most six
     processes on its card, so the node's eight ranks cannot be rehearsed here) = 8 + 8 + 8 + 7 blocks, i.e. launches
-    of 1024 and 896 units -- above three units per CU: k_blind_rotate7, as run_br dispatches -- a ragged gather, the gather of four partial
+    of 1024 and 896 units -- above three units per CU: k_blind_rotate8, as run_br dispatches -- a ragged gather, the gather of four partial
     maxima and the inner product's point-to-point step with 124 pairs dealt over four ranks"""
     import subprocess
     import sys as _sys
@@ -725,7 +725,7 @@ def test_sharded_runner_four_ranks_with_config4_share(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     line = _json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["checks"] == {"aes": True, "max": True, "inner_product": True}
-    assert line["blocks"] == 31 and line["ranks"] == 4 and line["blind_rotate_kernel"] == "k_blind_rotate7"
+    assert line["blocks"] == 31 and line["ranks"] == 4 and line["blind_rotate_kernel"] == "k_blind_rotate8"
 
 
 @pytest.mark.gpu
@@ -765,13 +765,14 @@ def test_trace_and_scheme_switch_ring_stress(rig256):
     assert np.array_equal(eng.scheme_switch_fourier(glev[:37]), f_o[:37])
 
 
-@pytest.mark.parametrize("variant", ["0", "4", "5", "6", "7"])
+@pytest.mark.parametrize("variant", ["0", "4", "5", "6", "7", "8"])
 @pytest.mark.parametrize("which", ["rig256", "rig768", "rig1024"])
 def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monkeypatch):
     """k_blind_rotate (hipcc, one wave per unit), k_blind_rotate4 / k_blind_rotate5 (generated assembly, two waves per SIMD,
     csrc/tx_br_asm*.inc; 5 = persistent workgroups with fair arbitration), k_blind_rotate6 (generated, three waves per
-    unit, csrc/tx_br3_asm.inc) and k_blind_rotate7 (the same loop, four units per twelve-wave workgroup: 13 units leave the
-    last workgroup with three shadow units), each forced on a small ragged launch: equals the oracle"""
+    unit, csrc/tx_br3_asm.inc), k_blind_rotate7 (the same loop, four units per twelve-wave workgroup in lockstep: 13 units leave the
+    last workgroup with three shadow units) and k_blind_rotate8 (that shape with software barriers per unit, csrc/tx_br3s_asm.inc: the
+    product's kernel between three and four units per CU), each forced on a small ragged launch: equals the oracle"""
     import txhip
     r = request.getfixturevalue(which)
     rng = np.random.default_rng(17)
@@ -784,7 +785,8 @@ def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monk
     e4 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)      # 13 units: a ragged last workgroup
     e4.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)
     got = e4.blind_rotate(lwe)
-    assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6", "7": "k_blind_rotate7"}[variant]
+    assert e4.last_blind_rotate_kernel() == {"0": "k_blind_rotate", "4": "k_blind_rotate4", "5": "k_blind_rotate5", "6": "k_blind_rotate6", "7": "k_blind_rotate7",
+                                               "8": "k_blind_rotate8"}[variant]
     one = e4.blind_rotate(lwe[5:6])                     # a single unit
     e4.close()
     assert np.array_equal(got, ref)
@@ -792,7 +794,7 @@ def test_every_blind_rotation_kernel_bit_identical(which, variant, request, monk
 
 
 def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
-    """the cooperative loop with the chip full of it, n = 768: 1024 units as the dispatch picks them (k_blind_rotate7: one
+    """the cooperative loop with the chip full of it, n = 768: 1024 units as the dispatch picks them (k_blind_rotate8: one
     twelve-wave workgroup of four units per CU), 1021 units (a ragged last workgroup: three shadow waves at every barrier),
     1024 units forced through k_blind_rotate6 (four three-wave workgroups per CU competing under the fair arbitration -- table
     of step counters, s_setprio -- some of them placed late) and 768 units as the dispatch picks them (k_blind_rotate6, three
@@ -810,10 +812,10 @@ def test_cooperative_blind_rotation_full_chip(rig768, monkeypatch):
     assert e0.last_blind_rotate_kernel() == "k_blind_rotate"
     e0.close()
     four = r.eng.blind_rotate(lwe)
-    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate7"
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate8"
     assert np.array_equal(four, one_wave) and np.array_equal(r.eng.blind_rotate(lwe), one_wave)
     assert np.array_equal(r.eng.blind_rotate(lwe[:1021]), one_wave[:1021])
-    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate7"
+    assert r.eng.last_blind_rotate_kernel() == "k_blind_rotate8"
     monkeypatch.setenv("TX_BR_VARIANT", "6")
     e6 = txhip.Engine(txhip.aes_tight(n=r.p.n), 0, experiments=True)
     e6.load_eval_keys(r.keys.bsk, r.keys.ksk, r.keys.auto, r.keys.ss)

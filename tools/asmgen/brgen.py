@@ -138,6 +138,10 @@ class Gen:
                 if isinstance(x, V): rd |= self.regs(x)
             if rd & self.valu_w[0]: self.p.emit("s_nop", Lit(1)); self.valu_w = [set(), set()]
             elif rd & self.valu_w[1]: self.p.emit("s_nop", Lit(0)); self.valu_w = [set(), self.valu_w[0]]
+        # v_readfirstlane / v_readlane of a VGPR the PREVIOUS instruction wrote: 1 wait state on gfx940+ (it would read the old
+        # value -- round 5, found on the hardware: a poll that compared a register with itself)
+        if op in ("v_readfirstlane_b32", "v_readlane_b32") and isinstance(a[1], V) and self.regs(a[1]) & self.valu_w[0]:
+            self.p.emit("s_nop", Lit(0)); self.valu_w = [set(), self.valu_w[0]]
         wrote = set()
         if op.startswith("v_") and a and isinstance(a[0], V):
             wrote = self.regs(a[0])

@@ -51,11 +51,26 @@ PF_ROWS = int(os.environ.get("BR3_PF_ROWS", 0))       # the key row touched this
 PF_LDS = 3 * TILE_STRIDE                 # from wave 0's tile: 1 KiB behind the three tiles, where the touched bytes are dropped
 FEPOCH = S(59)                           # launch number << 16: a word of another launch is not a competitor
 FAIR_LEADS = [int(x) for x in os.environ.get("BR3_FAIR_LEADS", "2,4,8").replace("-", ",").split(",")]   # lead (steps) below which the priority is 3, 2, 1
+# SOFT mode (round 5, k_blind_rotate8): several units share ONE workgroup (placement by construction, as k_blind_rotate7) but the
+# three waves of a unit meet at a SOFTWARE barrier of their own -- per-wave arrival words in LDS, polled -- instead of s_barrier,
+# which would span every unit of the workgroup (lockstep); the fair arbitration reads the units' step counters from LDS too.
+# The registers of the global fairness table are free in this mode and carry the LDS addresses.
+SFLAGS = S(66)                           # LDS address of this unit's arrival words (three used, 16 bytes)
+SMYFLAG = S(67)                          # ... of this wave's word
+SPROG = S(69)                            # LDS address of the workgroup's four step counters (16 bytes)
+SMYPROG = S(70)                          # ... of this unit's counter
+SBIDX = S(59)                            # barriers passed so far
+SSPIN = S(71)                            # polls left before a wave gives up waiting (a broken launch must still END)
+SOFT_SPIN = 1 << 18
+SOFT_SLEEP = int(os.environ.get("BR3_SOFT_SLEEP", 4))      # s_sleep units (64 cycles) between two polls (1, 2, 4 measured: 5.88, 5.86, 5.85 ms per 1024 units)
 
 
 class CoopGen(Gen):
-    def __init__(self, stamps=False, prio="", xhi_regs=None, xlo_regs=None, cu_fair=None):
+    def __init__(self, stamps=False, prio="", xhi_regs=None, xlo_regs=None, cu_fair=None, soft=None):
         super().__init__(stamps=stamps, prio=prio, fair=False)
+        self.soft = (os.environ.get("BR3_SOFT", "0") == "1") if soft is None else soft
+        if self.soft and os.environ.get("BR3_SOFT_NOFAIR") == "1": cu_fair = False      # debugging
+        assert not (self.soft and stamps), "the soft-barrier form uses the stamp accumulators' registers"
         # Fair arbitration between the (up to four) workgroups of a CU.  The SIMD arbiter serves the oldest wave first, so the
         # workgroups of a CU finish one after the other (1024 units: at 3.9, 5.0, 6.5 and 8.1 ms) and the last one runs with ever
         # fewer neighbours to fill its stalls; the vector pipe, 78 % busy while all four are there (SQ_ACTIVE_INST_VALU x 3 waves
@@ -80,8 +95,84 @@ class CoopGen(Gen):
         up to the barrier goes to `phase`, the wait at the barrier to accumulator 5)"""
         self.lg_wait_all()
         self.stamp(phase)
-        if "B" not in ABL3: self.p.emit("s_barrier")
+        if self.soft: self.soft_barrier()
+        elif "B" not in ABL3: self.p.emit("s_barrier")
         self.stamp(5)
+
+    SOFTQ = quad(E3, 0)                      # landing quad of the polls: free outside the multiply-accumulate
+
+    def soft_barrier(self):
+        """The unit's three waves meet without s_barrier: each writes the number of this barrier to its own word (a wave's LDS
+        operations execute in order, so whoever reads the word also finds what the wave stored before it), then polls the
+        unit's three words until none is behind.  s_sleep between polls leaves the SIMD to the other units' waves -- that is the
+        point: the units of a workgroup drift apart and fill each other's stalls.  A wave gives up after SOFT_SPIN polls: wrong
+        results (the tests would show them) instead of a launch that never ends."""
+        e = self.e
+        if "B" in ABL3: return
+        self.nlab += 1
+        poll, done = "L_sp%d_%%=" % self.nlab, "L_sd%d_%%=" % self.nlab
+        e("s_add_u32", SBIDX, SBIDX, Lit(1))
+        e("v_mov_b32", T0.lo(), SMYFLAG)
+        e("v_mov_b32", T0.hi(), SBIDX)
+        self.ds_write("ds_write_b32", T0.lo(), T0.hi())
+        e("v_mov_b32", T0.lo(), SFLAGS)
+        e("s_mov_b32", SSPIN, Lit(SOFT_SPIN))
+        self.p.label(poll)
+        self.ds_read("ds_read_b128", self.SOFTQ, T0.lo())
+        self.lg_wait_all()
+        e("v_min3_u32", T0.hi(), V(self.SOFTQ.i), V(self.SOFTQ.i + 1), V(self.SOFTQ.i + 2))
+        e("v_readfirstlane_b32", SG.TMP, T0.hi())
+        e("s_nop", Lit(3))
+        e("s_cmp_ge_u32", SG.TMP, SBIDX)
+        e("s_cbranch_scc1", done)
+        e("s_sub_u32", SSPIN, SSPIN, Lit(1))
+        e("s_cmp_eq_u32", SSPIN, Lit(0))
+        e("s_cbranch_scc1", done)
+        e("s_sleep", Lit(SOFT_SLEEP))
+        e("s_branch", poll)
+        self.p.label(done)
+        if os.environ.get("BR3_SOFT_HW") == "1": self.p.emit("s_barrier")      # debugging: the hardware barrier behind the soft one
+
+    def soft_fair_publish(self):
+        """loop head: this unit's step counter to LDS (its three waves store the same word), the four counters requested"""
+        e = self.e
+        e("v_mov_b32", T0.lo(), SMYPROG)
+        e("v_mov_b32", T0.hi(), SG.I)
+        self.ds_write("ds_write_b32", T0.lo(), T0.hi())
+        e("v_mov_b32", T0.lo(), SPROG)
+        self.ds_read("ds_read_b128", self.SOFTQ, T0.lo())
+
+    def soft_fair_apply(self):
+        """priority by this unit's lead over the slowest unit of the workgroup (a finished unit's counter is 0xFFFFFFF0)"""
+        e = self.e
+        self.c("---- fair arbitration between the units of the workgroup (LDS step counters) -> s_setprio")
+        words = [SG.CTV.lo(), SG.CTV.hi(), SG.TMP, SG.TMP2]
+        for k in range(4): e("v_readfirstlane_b32", words[k], V(self.SOFTQ.i + k))
+        e("s_nop", Lit(3))
+        e("s_min_u32", SG.TMP, SG.TMP, SG.TMP2)
+        e("s_min_u32", SG.CTV.lo(), SG.CTV.lo(), SG.CTV.hi())
+        e("s_min_u32", SG.TMP2, SG.TMP, SG.CTV.lo())
+        e("s_min_u32", SG.TMP2, SG.TMP2, SG.I)
+        e("s_sub_u32", SG.TMP, SG.I, SG.TMP2)
+        self.nlab += 1
+        done = "L_fp%d_%%=" % self.nlab
+        for prio, lead in zip((3, 2, 1), FAIR_LEADS):
+            nxt = "L_fq%d_%d_%%=" % (self.nlab, prio)
+            e("s_cmp_lt_u32", SG.TMP, Lit(lead))
+            e("s_cbranch_scc0", nxt)
+            e("s_setprio", Lit(prio))
+            e("s_branch", done)
+            self.p.label(nxt)
+        e("s_setprio", Lit(0))
+        self.p.label(done)
+
+    def soft_fair_finish(self):
+        e = self.e
+        e("s_setprio", Lit(0))
+        e("v_mov_b32", T0.lo(), SMYPROG)
+        e("v_mov_b32", T0.hi(), Lit(0xFFFFFFF0))
+        self.ds_write("ds_write_b32", T0.lo(), T0.hi())
+        self.lg_wait_all()
 
     # ---------------------------------------------------------------- one polynomial forward (fft_fwd of tx_device.hpp)
     def fwd1(self, v, xq, before_pass3=None):
@@ -168,7 +259,8 @@ class CoopGen(Gen):
         e("v_mov_b32", R10, Lit(0))
         self.gload("global_load_dwordx2", V(10, 2), R10, SG.CT, offset=0)     # mask element 0
         e("s_mov_b32", SG.I, Lit(0))
-        if self.cu_fair: self.fair_request()
+        if self.soft: e("s_mov_b32", SBIDX, Lit(0))
+        elif self.cu_fair: self.fair_request()
         self.lg_wait_all()
         if self.stamps:
             for k in range(NSTAMP):
@@ -260,7 +352,9 @@ class CoopGen(Gen):
         self.setprio("R")
         self.c("---- modswitch(ct[i]) -> rot; base = (lane - rot) mod 2N")
         self.p.emit("s_waitcnt", vm=0); self.vmq.clear()
-        if self.cu_fair: self.fair_step()
+        if self.soft:
+            if self.cu_fair: self.soft_fair_publish()
+        elif self.cu_fair: self.fair_step()
         self.key_prefetch()
         e("v_readfirstlane_b32", SG.CTV.hi(), R11)
         e("s_nop", Lit(3))
@@ -280,6 +374,7 @@ class CoopGen(Gen):
             e("v_bfe_i32", SGN3[m], t, Lit(4), Lit(1))          # 0 / -1: coefficient comes from the negated half
             e("v_and_b32", t, Lit(15), t)
             e("v_lshl_add_u32", RA3[m], t, Lit(9), R11)
+        if self.soft and self.cu_fair: self.soft_fair_apply()       # (the counters requested at the loop head have landed)
         # next mask element (index min(i+1, n-1)), a step ahead of its use
         e("s_add_u32", SG.TMP, SG.I, Lit(1))
         e("s_cmp_lt_u32", SG.TMP, SG.NSTEP)
@@ -364,7 +459,7 @@ class CoopGen(Gen):
             for kk in (k, k + 1):
                 if kk + NG < len(stream): issue(kk + NG)
                 if kk + NL < len(stream): fetch(kk + NL)
-        if self.cu_fair: self.fair_request()                    # (the landing quads of the published transforms are free again)
+        if self.cu_fair and not self.soft: self.fair_request()  # (the landing quads of the published transforms are free again)
         self.stamp(2)
         # ---- inverse; the tiles are free for its exchanges once every wave has read what it needs
         self.setprio("I")
@@ -402,7 +497,9 @@ class CoopGen(Gen):
         e = self.e
         self.c("---- epilogue: store this wave's polynomial (OUT points at it)")
         self.vm_wait_all()
-        if self.cu_fair: self.fair_finish()
+        if self.soft:
+            if self.cu_fair: self.soft_fair_finish()
+        elif self.cu_fair: self.fair_finish()
         e("v_lshlrev_b32", L8, Lit(3), LANE)                    # (register 9: the published-transform address is dead)
         e("v_add_u32", T0.lo(), Lit(4096), L8)
         for m in range(16):
@@ -415,6 +512,21 @@ class CoopGen(Gen):
                 e("v_mov_b32", T1.lo(), ST_ACC[k].lo()); e("v_mov_b32", T1.hi(), ST_ACC[k].hi())
                 self.gstore("global_store_dwordx2", T0.hi(), T1, ST_DBG, offset=8 * k)
             self.vm_wait_all()
+
+
+def render_inc_soft(prog):
+    """soft-barrier form: %0 ct (64), %1 column c of bsk row 0 (64), %2 out + c N (64), %3 n, %4 this wave's tile, %5 the unit's first
+    tile, %6 LDS address of the unit's arrival words, %7 of this wave's word, %8 of the workgroup's step counters, %9 of this unit's
+    counter, %10 the tie mode"""
+    head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
+            "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE, "s_mov_b32 %s, %%5" % TILE0,
+            "s_mov_b32 %s, %%6" % SFLAGS, "s_mov_b32 %s, %%7" % SMYFLAG, "s_mov_b32 %s, %%8" % SPROG, "s_mov_b32 %s, %%9" % SMYPROG,
+            "s_mov_b32 %s, %%10" % SG.TIEMODE]
+    lines = ["  " + h for h in head] + prog.render()
+    out = ["// generated by tools/asmgen/brgen3.py (soft-barrier form) -- do not edit"]
+    for l in lines:
+        out.append('"%s\\n"' % l.replace('"', '\\"'))
+    return "\n".join(out) + "\n"
 
 
 def render_inc(prog, stamps=False):
@@ -442,6 +554,7 @@ if __name__ == "__main__":
     prog = CoopGen(prio=os.environ.get("BR3_PRIO", "")).build()
     if len(sys.argv) > 2 and sys.argv[1] == "--out":
         open(os.path.join(sys.argv[2], "tx_br3_asm.inc"), "w").write(render_inc(prog))
+        open(os.path.join(sys.argv[2], "tx_br3s_asm.inc"), "w").write(render_inc_soft(CoopGen(soft=True, prio=os.environ.get("BR3_PRIO", "")).build()))
         open(os.path.join(sys.argv[2], "tx_br3_asm_stamps.inc"), "w").write(render_inc(CoopGen(stamps=True).build(), stamps=True))
         open(os.path.join(sys.argv[2], "tx_br3_asm_clobbers.inc"), "w").write(render_clobbers())
         open(os.path.join(sys.argv[2], "tx_br3_asm_consts.inc"), "w").write(

@@ -1,5 +1,5 @@
 """exploratory soak: several key seeds x an instance of BLOCKS AES blocks (default 64 = medium; 8 = the per-GPU share of an 8-GPU run:
-k_blind_rotate7; 6, 4, 3 = the fair cooperative kernel), ECB and CTR, product-only path:  tools/soak.py first_seed last_seed [BLOCKS] [tfhe]
+k_blind_rotate8; 6, 4, 3 = the fair cooperative kernel), ECB and CTR, product-only path:  tools/soak.py first_seed last_seed [BLOCKS] [tfhe]
 (a fourth argument `tfhe`: every decomposition under tfhe-rs' tie rule, tx_set_decomposer_tie_rule(ctx, TX_TIE_TFHE_RS) -- the rule whose
 top-digit mean costs the bootstrap 3.7 sigma of margin: wrong plaintext bits are EXPECTED at a rate of about one bootstrap in 10^6)"""
 import sys, os, time

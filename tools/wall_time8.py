@@ -1,6 +1,6 @@
 """exploratory: per-family kernel times of tx_transcipher on 8 CTR blocks (the per-GPU share of an 8-GPU run), TX_LIB selects a build"""
 import sys, os, time
-sys.path.insert(0, "temp-fhe-transciphering_amd/python")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "temp-fhe-transciphering_amd", "python"))
 import numpy as np, txhip, txclient, ctypes as C
 if os.environ.get('TX_LIB'): txhip.LIB_PATH = os.environ['TX_LIB']
 p = txhip.aes_tight(n=768)
