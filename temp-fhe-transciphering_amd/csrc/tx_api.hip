@@ -171,7 +171,7 @@ extern "C" tx_ctx *tx_create(const tx_params *p, int device)
 #endif
         if (!ok || (c->trace_variant != 0 && c->trace_variant != 4) || (c->ss_variant != 0 && c->ss_variant != 4) ||
             (c->lut_variant != 0 && c->lut_variant != 4)) {
-            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5, 6 or 7 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT, TX_SS_VARIANT and TX_LUT_VARIANT 0 or 4");
+            fail("tx_create: TX_BR_VARIANT must be 0, 4, 5, 6, 7 or 8 (3 only in a TXD_WITH_BR3 build), TX_TRACE_VARIANT, TX_SS_VARIANT and TX_LUT_VARIANT 0 or 4");
             tx_destroy(c); return nullptr;
         }
     }

@@ -454,7 +454,7 @@ def test_create_failure_paths_release_the_context(monkeypatch):
     product library reads no environment: the same values leave it unmoved"""
     import txhip
     p = txhip.aes_tight(n=256)
-    for name, bad in (("TX_BR_VARIANT", "8"), ("TX_BR_VARIANT", "x"), ("TX_TRSS_WGS_PER_CU", "0"), ("TX_BR5_WGS", "-3"),
+    for name, bad in (("TX_BR_VARIANT", "9"), ("TX_BR_VARIANT", "x"), ("TX_TRSS_WGS_PER_CU", "0"), ("TX_BR5_WGS", "-3"),
                       ("TX_TRACE_VARIANT", "2"), ("TX_BR_VARIANT", "3")):
         monkeypatch.setenv(name, bad)
         for _ in range(34):
