@@ -97,15 +97,20 @@ def stage_times(n_gpus, seed):
     # process (torch loaded, gigabytes of device memory mapped) costs tens of milliseconds that are not the stage's
     env = dict(os.environ, TX_DEVICES=",".join(str(i) for i in range(n_gpus)))
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python", "run_submission.py"), "2",
-                            "--root", root, "--seed", str(seed), "--fhe_seed", str(seed + 7)], capture_output=True, text=True, env=env, timeout=600)
-        res = json.load(open(os.path.join(root, "measurements", "medium", "results.json")))
-        st = res["per_stage"]
-        return {"aes_decryption": st["7: server_encrypted_aes_decryption"], "compute": st["8: server_encrypted_compute"],
-                "verified": r.returncode == 0 and "AES decryption: PASS; max: PASS" in r.stdout, "devices": n_gpus,
-                "total_latency_s": res["total_latency_s"],
+        runs = []
+        for _ in range(2):          # twice: the first run of a fresh box pays for cold libraries and binaries (reported as first_run)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "temp-fhe-transciphering_amd", "python", "run_submission.py"), "2",
+                                "--root", root, "--seed", str(seed), "--fhe_seed", str(seed + 7)], capture_output=True, text=True, env=env, timeout=600)
+            res = json.load(open(os.path.join(root, "measurements", "medium", "results.json")))
+            st = res["per_stage"]
+            runs.append({"aes_decryption": st["7: server_encrypted_aes_decryption"], "compute": st["8: server_encrypted_compute"],
+                         "verified": r.returncode == 0 and "AES decryption: PASS; max: PASS" in r.stdout, "total_latency_s": res["total_latency_s"]})
+        return {"aes_decryption": runs[1]["aes_decryption"], "compute": runs[1]["compute"],
+                "verified": runs[0]["verified"] and runs[1]["verified"], "devices": n_gpus, "total_latency_s": runs[1]["total_latency_s"],
+                "first_run": {"aes_decryption": runs[0]["aes_decryption"], "compute": runs[0]["compute"]},
                 "note": "wall seconds of the stage PROCESSES of one medium instance (process start, HIP initialisation, key files -> "
-                        "device, the computation, result file), max mini-workload; the harness's clock, not `value`'s"}
+                        "device, the computation, result file), max mini-workload; the harness's clock, not `value`'s; the instance is "
+                        "run twice, the second run is reported (first_run: the first, with cold libraries on a fresh box)"}
     except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as ex:
         return {"aes_decryption": None, "compute": None, "verified": False, "devices": n_gpus, "error": repr(ex)}
     finally:
