@@ -917,20 +917,24 @@ static int transcipher_impl(tx_ctx *c, const uint8_t *ct, size_t n_blocks, const
     uint64_t *buf[2] = { c->res, c->res2 };
     size_t prev_b0 = 0, prev_nb = 0; int prev = -1;
     int k = 0;
+    // a failure half way must not leave a copy in flight into the caller's memory: both streams are drained before the error returns
+    auto drained = [&](int rc) { if (rc) { const std::string keep = g_err; hipStreamSynchronize(c->copy_stream); hipStreamSynchronize(c->stream); g_err = keep; } return rc; };
+#define PIPE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return drained(fail(std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
     for (size_t b0 = 0; b0 < n_blocks; b0 += chunk, k ^= 1) {
         const size_t nb = std::min(chunk, n_blocks - b0);
         // buf[k] was the source of the copy two chunks ago: the compute stream may not write it before that copy is done
-        if (b0 >= 2 * chunk) HIP_OK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
-        if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, buf[k], reference_order, buf[k])) return -1;
-        HIP_OK(hipEventRecord(c->ev_done[k], c->stream));
-        HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_done[k], 0));
-        HIP_OK(hipMemcpyAsync(out + b0 * 128 * BIG, buf[k], nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_OK(hipEventRecord(c->ev_copied[k], c->copy_stream));
-        if (prev >= 0 && cb) { HIP_OK(hipEventSynchronize(c->ev_copied[prev])); cb(user, prev_b0, prev_nb); }
+        if (b0 >= 2 * chunk) PIPE_OK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+        if (transcipher_chunk(c, ct + b0 * 16, nb, iv, b0, rounds_done, buf[k], reference_order, buf[k])) return drained(-1);
+        PIPE_OK(hipEventRecord(c->ev_done[k], c->stream));
+        PIPE_OK(hipStreamWaitEvent(c->copy_stream, c->ev_done[k], 0));
+        PIPE_OK(hipMemcpyAsync(out + b0 * 128 * BIG, buf[k], nb * 128 * BIG * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        PIPE_OK(hipEventRecord(c->ev_copied[k], c->copy_stream));
+        if (prev >= 0 && cb) { PIPE_OK(hipEventSynchronize(c->ev_copied[prev])); cb(user, prev_b0, prev_nb); }
         prev = k; prev_b0 = b0; prev_nb = nb;
     }
-    HIP_OK(hipStreamSynchronize(c->copy_stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    PIPE_OK(hipStreamSynchronize(c->copy_stream));
+    PIPE_OK(hipStreamSynchronize(c->stream));
+#undef PIPE_OK
     if (cb) cb(user, prev_b0, prev_nb);
     return timing_collect(c);
 }
