@@ -1,4 +1,4 @@
-"""Generator of the PAIRED blind-rotation loop: TWO waves work on ONE unit, two to one (k_blind_rotate7, launches of three to
+"""Generator of the PAIRED blind-rotation loop: TWO waves work on ONE unit, two to one (an experiment of round 3 that is not in the library -- its parked wrapper is tools/asmgen/k_blind_rotate7.hip.txt, not the k_blind_rotate7 of tx_br2.hpp --, launches of three to
 four units per CU: the 8-blocks-per-GPU share of the medium instance on an 8-GPU node).
 
 The cooperative loop of brgen3.py (three waves per unit, one per polynomial) shortens a CMux chain by 2.4x when the chip is
