@@ -46,6 +46,7 @@ struct tx_ctx {
     cplx *bsk_f = nullptr, *ksk_f = nullptr, *auto_f = nullptr, *ss_f = nullptr;
     size_t auto_split_stride = 0;
     cplx *tw = nullptr, *tw256 = nullptr;
+    uint32_t *br8_fault = nullptr;          // host-mapped word: a wave of k_blind_rotate8 that gave up waiting at a software barrier stores 1 (checked per call)
     uint32_t *fair_tab = nullptr;           // k_blind_rotate6: step counters of the workgroups of every CU (tx_br2.hpp)
     uint32_t br6_epoch = 0;                 // launch number of k_blind_rotate6: a table word of another launch is not a competitor
     int num_cus = 0;
@@ -134,6 +135,8 @@ static int upload_tables(tx_ctx *c)
     HIP_OK(hipMemcpy(c->tw256, t2.data(), t2.size() * sizeof(cplx), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->fair_tab, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t)));
     HIP_OK(hipMemset(c->fair_tab, 0, (size_t)FAIR_TAB_ENTRIES * FAIR_TAB_WORDS * sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc((void **)&c->br8_fault, sizeof(uint32_t), hipHostMallocMapped));
+    *c->br8_fault = 0;
     return 0;
 }
 
@@ -227,6 +230,7 @@ extern "C" void tx_destroy(tx_ctx *c)
     free_ws(c);
     hipFree(c->bsk_f); hipFree(c->ksk_f); hipFree(c->auto_f); hipFree(c->ss_f);
     hipFree(c->tw); hipFree(c->tw256); hipFree(c->fair_tab); hipFree(c->luts); hipFree(c->ctr_luts);
+    if (c->br8_fault) hipHostFree(c->br8_fault);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -273,6 +277,12 @@ static void timing_reset(tx_ctx *c)
 }
 static int timing_collect(tx_ctx *c)
 {
+    // every entry point ends here, behind its last synchronisation: a wave of k_blind_rotate8 that gave up waiting at a software
+    // barrier (2^18 polls: a fault, never seen) has made the launch's results invalid -- the call fails, loudly
+    if (c->br8_fault && *c->br8_fault) {
+        *c->br8_fault = 0;
+        return fail("k_blind_rotate8: a wave gave up waiting at a software barrier; the results of this call are invalid");
+    }
     // what ran is taken from the launches themselves (launch_br), so it is right without events too
     tx_timing &t = c->timing;
     t.units_br_main = 0; t.n_br_main = 0; t.units_blind_rotate = 0;
@@ -586,7 +596,7 @@ static void launch_br(tx_ctx *c, int variant, const uint64_t *in, size_t count, 
     if (variant == 8) {
         ev_begin(c, F_BR, "k_blind_rotate8", count);
         hipLaunchKernelGGL(k_blind_rotate8, dim3((count + BR7_UNITS - 1) / BR7_UNITS), dim3(768), LDS_BYTES_BR7, c->stream, in, acc, (int)count, n,
-                           c->bsk_f, c->tw, c->tie_on);
+                           c->bsk_f, c->tw, c->tie_on, c->br8_fault);
     } else if (variant == 6) {
         // launch number 0 = no arbitration: with at most one workgroup per CU there is nobody to be fair to
         uint32_t ep = count <= (size_t)c->num_cus ? 0u : (++c->br6_epoch & 0x7FFFu);          // 15 bits above the 16-bit step count of a table word

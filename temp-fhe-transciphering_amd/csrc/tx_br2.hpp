@@ -624,13 +624,14 @@ __device__ __forceinline__ uint32_t lds_addr(unsigned char *p)
 // shape, section "Placement" of DESIGN_HISTORY.md) -- WITHOUT k_blind_rotate7's lockstep: the generated loop's soft-barrier form (tools/asmgen/brgen3.py, SOFT: tx_br3s_asm.inc).
 // The three waves of a unit meet at arrival words in LDS that they poll (s_sleep between polls), the four units drift apart and
 // fill each other's stalls, and the fair arbitration between them reads their step counters from LDS.  No s_barrier behind the
-// __syncthreads below; a wave gives up polling after 2^18 tries (wrong results, never a launch that does not end).  Same
+// __syncthreads below; a wave gives up polling after 2^18 tries and stores 1 to the context's fault word (the launch ENDS, its
+// results are invalid, and the host fails the call: tx_api.hip timing_collect).  Same
 // arithmetic, same results.  Inside the round pipeline 5.85-5.95 ms per 1024 units against 6.44 for k_blind_rotate7 (same box,
 // alternating, profiles/r5g_*); without the fair arbitration 6.8 ms.  The spare kilobyte behind the twelve tiles holds the arrival words (16 bytes per unit) and the four
 // step counters.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_blind_rotate8(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, int tie_on)
+void k_blind_rotate8(const uint64_t *lwe, uint64_t *acc_out, int count, int n, const cplx *bsk_f, const cplx *tw_g, int tie_on, uint32_t *fault)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     cplx *tw = reinterpret_cast<cplx *>(lds);
@@ -669,7 +670,7 @@ void k_blind_rotate8(const uint64_t *lwe, uint64_t *acc_out, int count, int n, c
     asm volatile(
 #include "tx_br3s_asm.inc"
         :
-        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(flags), "s"(myflag), "s"(prog), "s"(myprog), "s"(tie_on)
+        : "s"(ct), "s"(col), "s"(out), "s"(n), "s"(tile_addr), "s"(tile0_addr), "s"(flags), "s"(myflag), "s"(prog), "s"(myprog), "s"(tie_on), "s"(fault)
         :
 #include "tx_br3_asm_clobbers.inc"
     );

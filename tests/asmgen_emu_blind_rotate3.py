@@ -109,6 +109,7 @@ def main():
         ct_buf = lwe.copy().view(np.uint8)
         key_buf = key.reshape(-1).view(np.uint8).copy()
         out_buf = np.zeros(KP * N * 8, np.uint8)
+        fault_buf = np.zeros(4, np.uint8)           # the context's fault word (soft-barrier form)
         SG = brgen.SG
         emus = []
         for c in range(3):
@@ -124,6 +125,8 @@ def main():
             e.s[brgen3.TILE0.i] = TW_BYTES
             e.s[SG.TIEMODE.i] = 0 if os.environ.get('EMU_TIE') == 'tfhe' else 1
             if SOFT:
+                e.g.append((0x6000_0000, fault_buf))
+                e.s[brgen3.SFAULT.i] = 0x6000_0000; e.s[brgen3.SFAULT.i + 1] = 0
                 e.s[brgen3.SFLAGS.i] = FLAGS; e.s[brgen3.SMYFLAG.i] = FLAGS + 4 * c
                 e.s[brgen3.SPROG.i] = FLAGS + 16; e.s[brgen3.SMYPROG.i] = FLAGS + 16 + 4 * 1        # this unit is unit 1 of its workgroup
             if os.environ.get("BR_STAMPS"):
@@ -134,10 +137,20 @@ def main():
         if SOFT:
             # the other units' step counters: one two steps ahead, one finished, one behind (every priority path over three steps)
             lds[FLAGS + 16: FLAGS + 32].view(np.uint32)[:] = [2, 0, 0xFFFFFFF0, 0]
+            if os.environ.get("BR3_SOFT_SPIN"):
+                # the give-up path (generator built with a poll budget of a few): wave 0 runs ALONE, its partners never arrive --
+                # it must reach the end of the program all the same, and the fault word must say so
+                emus[0].yield_on_sleep = True
+                for _ in emus[0].run_gen(prog): pass
+                gave_up = int(fault_buf.view(np.uint32)[0]) == 1
+                print("soft barriers, wave 0 alone with a poll budget of %s: ended, fault word %d -> %s" %
+                      (os.environ["BR3_SOFT_SPIN"], fault_buf.view(np.uint32)[0], "GAVE-UP-REPORTED" if gave_up else "NOT REPORTED"))
+                sys.exit(0 if gave_up else 1)
             run_group_soft(emus, prog, order)
             same = np.array_equal(out_buf.view(np.uint64).reshape(KP, N), ref)
             cnt = lds[FLAGS: FLAGS + 32].view(np.uint32)
             same = same and list(cnt[:3]) == [2 * steps] * 3 and cnt[4 + 1] == 0xFFFFFFF0 and cnt[4] == 2 and cnt[4 + 2] == 0xFFFFFFF0
+            same = same and int(fault_buf.view(np.uint32)[0]) == 0
             ok = ok and same
             print("soft barriers, steps %d seed %d order %s: %d instructions per wave, %.1f s -> %s" %
                   (steps, seed, order, emus[0].nexec, time.time() - t, "BIT-IDENTICAL" if same else "MISMATCH"))

@@ -64,6 +64,10 @@ def test_cooperative_loop_with_soft_barriers_equals_oracle(oracle):
         assert r.returncode == 0 and r.stdout.count("BIT-IDENTICAL") == 2, r.stdout + r.stderr
     r = subprocess.run([sys.executable, exe, "2", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR3_SOFT="1", BR3_ABL="B"))
     assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout + r.stderr
+    # a wave whose partners never arrive gives up after its poll budget, ENDS, and says so in the context's fault word (the host
+    # then fails the call: csrc/tx_api.hip timing_collect)
+    r = subprocess.run([sys.executable, exe, "2", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BR3_SOFT="1", BR3_SOFT_SPIN="3"))
+    assert r.returncode == 0 and "GAVE-UP-REPORTED" in r.stdout, r.stdout + r.stderr
     sys.path.insert(0, GEN)
     import gcn
     from gcn import V, S, Lit

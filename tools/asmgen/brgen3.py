@@ -61,7 +61,8 @@ SPROG = S(69)                            # LDS address of the workgroup's four s
 SMYPROG = S(70)                          # ... of this unit's counter
 SBIDX = S(59)                            # barriers passed so far
 SSPIN = S(71)                            # polls left before a wave gives up waiting (a broken launch must still END)
-SOFT_SPIN = 1 << 18
+SFAULT = S(72, 2)                        # global address of the context's fault word: a wave that gave up stores 1 there (the call then fails)
+SOFT_SPIN = int(os.environ.get("BR3_SOFT_SPIN", 1 << 18))      # (the emulator test of the give-up path sets 3)
 SOFT_SLEEP = int(os.environ.get("BR3_SOFT_SLEEP", 4))      # s_sleep units (64 cycles) between two polls (1, 2, 4 measured: 5.88, 5.86, 5.85 ms per 1024 units)
 
 
@@ -127,7 +128,16 @@ class CoopGen(Gen):
         e("s_cbranch_scc1", done)
         e("s_sub_u32", SSPIN, SSPIN, Lit(1))
         e("s_cmp_eq_u32", SSPIN, Lit(0))
-        e("s_cbranch_scc1", done)
+        nap = "L_sn%d_%%=" % self.nlab
+        e("s_cbranch_scc0", nap)
+        # gave up: the results of this launch are invalid.  Say so -- the host fails the call -- and go on to the end.  (Emitted
+        # outside the wait-count model: the store is retired right here, with whatever else was in flight.)
+        self.p.emit("v_mov_b32", T0.lo(), Lit(0))
+        self.p.emit("v_mov_b32", T0.hi(), Lit(1))
+        self.p.emit("global_store_dword", T0.lo(), T0.hi(), SFAULT, offset=0)
+        self.p.emit("s_waitcnt", vm=0)
+        e("s_branch", done)
+        self.p.label(nap)
         e("s_sleep", Lit(SOFT_SLEEP))
         e("s_branch", poll)
         self.p.label(done)
@@ -517,11 +527,11 @@ class CoopGen(Gen):
 def render_inc_soft(prog):
     """soft-barrier form: %0 ct (64), %1 column c of bsk row 0 (64), %2 out + c N (64), %3 n, %4 this wave's tile, %5 the unit's first
     tile, %6 LDS address of the unit's arrival words, %7 of this wave's word, %8 of the workgroup's step counters, %9 of this unit's
-    counter, %10 the tie mode"""
+    counter, %10 the tie mode, %11 the context's fault word (64)"""
     head = ["s_mov_b64 %s, %%0" % SG.CT, "s_mov_b64 %s, %%1" % SG.ROW, "s_mov_b64 %s, %%2" % SG.OUT,
             "s_mov_b32 %s, %%3" % SG.NSTEP, "s_mov_b32 %s, %%4" % SG.TILE, "s_mov_b32 %s, %%5" % TILE0,
             "s_mov_b32 %s, %%6" % SFLAGS, "s_mov_b32 %s, %%7" % SMYFLAG, "s_mov_b32 %s, %%8" % SPROG, "s_mov_b32 %s, %%9" % SMYPROG,
-            "s_mov_b32 %s, %%10" % SG.TIEMODE]
+            "s_mov_b32 %s, %%10" % SG.TIEMODE, "s_mov_b64 %s, %%11" % SFAULT]
     lines = ["  " + h for h in head] + prog.render()
     out = ["// generated by tools/asmgen/brgen3.py (soft-barrier form) -- do not edit"]
     for l in lines:
