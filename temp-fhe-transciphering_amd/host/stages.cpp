@@ -261,10 +261,11 @@ struct EvalKeyFiles {
             ss.size() != txc_ss_words(&prm)) throw std::runtime_error("public_keys/*.bin do not match the AES_TIGHT parameter set");
     }
 };
-tx_ctx *make_context(const tx_params &prm, int dev, const EvalKeyFiles &k, size_t reserve_blocks = 0)
+tx_ctx *make_context(const tx_params &prm, int dev, const EvalKeyFiles &k, size_t reserve_blocks = 0, Clock *clk = nullptr, const std::string &tag = "")
 {   // SRV_AES:646-687: conversion of the keys to their evaluation form, here on the GPU, once per context
     tx_ctx *c = tx_create(&prm, dev);
     if (!c) throw std::runtime_error(std::string("tx_create (device ") + std::to_string(dev) + "): " + tx_last_error());
+    if (clk) clk->mark("context_created" + tag);            // HIP runtime up, stream, twiddle tables
     if (reserve_blocks) tx_reserve(c, reserve_blocks);       // the workspace is then allocated underneath the key transforms
     if (tx_load_eval_keys(c, k.bsk.data(), k.bsk.size(), k.ksk.data(), k.ksk.size(), k.au.data(), k.au.size(), k.ss.data(), k.ss.size())) {
         std::string m = std::string("tx_load_eval_keys: ") + tx_last_error();
@@ -373,7 +374,7 @@ int server_encrypted_aes_decryption(int size)
         uint64_t *host = land.base;
         tx_ctx *c = nullptr;
         try {
-            c = make_context(prm, devs[r], keys, cnt);
+            c = make_context(prm, devs[r], keys, cnt, &clk, tag);
             clk.mark("keys_resident" + tag);
             if (size == 0) check(tx_load_round_luts(c, luts.data(), luts.size()), "tx_load_round_luts");
             else check(tx_load_ctr_luts(c, luts.data(), luts.size()), "tx_load_ctr_luts");
@@ -427,7 +428,7 @@ int server_encrypted_compute(int size, int mini_workload)
     struct Release { std::vector<tx_ctx *> &c; bool armed = true; ~Release() { if (armed) for (auto x : c) if (x) tx_destroy(x); } } release{ ctx };
     on_threads(D, [&](size_t r) {
         const std::string tag = D > 1 ? "[" + std::to_string(r) + "]" : "";
-        ctx[r] = make_context(prm, devs[r], keys);
+        ctx[r] = make_context(prm, devs[r], keys, 0, &clk, tag);
         clk.mark("keys_resident" + tag);
         uint64_t *dst = D == 1 ? outv.data() : part.data() + r * v16;
         if (mini_workload == 1) {
